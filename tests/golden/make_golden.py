@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Regenerates the committed golden fixtures.  Run in the BUILD container (needs g++ and, for
+the kernel fixtures, /root/reference so that oracle/build_ref.sh can compile the reference's
+own kernel).  The GPU box only reads the fixtures.
+
+  rng_golden.json           first 256 draws of the reference's input generator (libstdc++)
+  ref_<cfg>_<N>x<K>x<M>.npz C computed by the REFERENCE'S OWN kernel sources
+                            (kernel/{Compute,Memory,Top}.cpp via oracle/_ref) on the
+                            reference's seeded inputs; A and B are not stored (regenerated from
+                            the seed by the oracle's generator, whose draws rng_golden.json pins).
+  ref_checksums.json        sha256 of C for the reference's CTest shape 513x528x528
+                            (CMakeLists.txt:155-159) per config.
+"""
+import hashlib
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import _oracle  # noqa: E402
+
+
+def main():
+    exe = os.path.join(HERE, "rng_reference.bin")
+    subprocess.run(["g++", "-O1", "-o", exe, os.path.join(HERE, "rng_reference.cpp")], check=True)
+    out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
+    os.remove(exe)
+    json.loads(out)
+    with open(os.path.join(HERE, "rng_golden.json"), "w") as f:
+        f.write(out)
+
+    subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "-s"], check=True, stdout=subprocess.DEVNULL)
+    small = [(37, 32, 48), (1, 16, 16), (300, 64, 272)]
+    checks = {}
+    for dtype, mp, rd in [("float", "Multiply", "Add"), ("int", "Multiply", "Add"), ("float", "Add", "Min")]:
+        if not _oracle.ref_available(dtype, mp, rd):
+            print("skip (oracle/_ref not built):", dtype, mp, rd)
+            continue
+        for (n, k, m) in small:
+            a, b = _oracle.fill(dtype, n, k, m)
+            c = _oracle.ref_kernel(dtype, mp, rd, a, b)
+            np.savez_compressed(os.path.join(HERE, f"ref_{dtype}_{mp}_{rd}_{n}x{k}x{m}.npz"), c=c,
+                                a_sha256=hashlib.sha256(a.tobytes()).hexdigest(),
+                                b_sha256=hashlib.sha256(b.tobytes()).hexdigest())
+        n, k, m = 513, 528, 528
+        a, b = _oracle.fill(dtype, n, k, m)
+        c = _oracle.ref_kernel(dtype, mp, rd, a, b)
+        checks[f"{dtype}_{mp}_{rd}"] = {
+            "shape": [n, k, m],
+            "a_sha256": hashlib.sha256(a.tobytes()).hexdigest(),
+            "b_sha256": hashlib.sha256(b.tobytes()).hexdigest(),
+            "c_sha256": hashlib.sha256(c.tobytes()).hexdigest(),
+        }
+    with open(os.path.join(HERE, "ref_checksums.json"), "w") as f:
+        json.dump(checks, f, indent=1, sort_keys=True)
+    print("golden fixtures written to", HERE)
+
+
+if __name__ == "__main__":
+    main()
