@@ -1,0 +1,170 @@
+"""gemm_hls_amd -- MI355X (gfx950) implementation of spcl/gemm_hls's hot path
+C = A (map, reduce) B behind the reference's own boundary.
+
+The product is the C-ABI shared library ``libmm_gemm_amd.so`` (``include/mm_gemm.h``) and the C++
+host runner ``bin/RunHardware.exe``.  This module is the thin Python binding used by the tests
+and ``bench.py``: ctypes onto the C ABI, with PyTorch only as plumbing for device memory, streams
+and ``torch.distributed``.  There is no CPU fallback: importing works without a GPU (so the
+symbol checks can run), every compute call raises ``MMError`` without one.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmm_gemm_amd.so")
+
+# numerically identical to include/mm_gemm.h (asserted by tests/test_capi_symbols.py)
+DTYPES = {"float": 0, "double": 1, "half": 2, "int8_t": 3, "uint8_t": 4, "int16_t": 5,
+          "uint16_t": 6, "int": 7, "unsigned": 8, "long": 9, "unsigned long": 10}
+OPS = {"Add": 0, "Multiply": 1, "And": 2, "Min": 3, "Max": 4}
+PATH_AUTO, PATH_ORDERED = 0, 1
+
+EXPORTS = ["mm_init", "mm_alloc", "mm_free", "mm_copy_to_device", "mm_copy_to_host",
+           "mm_fill_device", "mm_gemm_launch", "mm_gemm_enqueue", "mm_gemm_multi_device",
+           "MatrixMultiplicationKernel", "mm_set_default_config", "mm_dtype_size",
+           "mm_config_supported", "mm_kernel_name", "mm_last_error"]
+
+
+class MMError(RuntimeError):
+    pass
+
+
+class Config(ctypes.Structure):
+    _fields_ = [("dtype", ctypes.c_int), ("map_op", ctypes.c_int), ("reduce_op", ctypes.c_int),
+                ("path", ctypes.c_int), ("layout_a", ctypes.c_int)]
+
+
+_lib = None
+
+
+def lib():
+    """The loaded C-ABI library.  Raises (never falls back) if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MMError(f"{LIB_PATH} is missing: run `python gemm_hls_amd/build.py` "
+                          "(or __graft_entry__.build()); there is no fallback implementation")
+        L = ctypes.CDLL(LIB_PATH)
+        vp, u, i, sz = ctypes.c_void_p, ctypes.c_uint, ctypes.c_int, ctypes.c_size_t
+        cfgp = ctypes.POINTER(Config)
+        L.mm_init.argtypes = [ctypes.POINTER(i)]
+        L.mm_alloc.argtypes = [i, sz, ctypes.POINTER(vp)]
+        L.mm_free.argtypes = [i, vp]
+        L.mm_copy_to_device.argtypes = [i, vp, vp, sz]
+        L.mm_copy_to_host.argtypes = [i, vp, vp, sz]
+        L.mm_fill_device.argtypes = [i, i, vp, sz, ctypes.c_ulonglong]
+        L.mm_gemm_launch.argtypes = [i, cfgp, vp, vp, vp, u, u, u, ctypes.POINTER(ctypes.c_double)]
+        L.mm_gemm_enqueue.argtypes = [vp, cfgp, vp, vp, vp, u, u, u]
+        L.mm_gemm_multi_device.argtypes = [i, cfgp, vp, vp, vp, u, u, u, ctypes.POINTER(ctypes.c_double)]
+        L.MatrixMultiplicationKernel.argtypes = [vp, vp, vp, u, u, u]
+        L.MatrixMultiplicationKernel.restype = None
+        L.mm_set_default_config.argtypes = [cfgp]
+        L.mm_dtype_size.argtypes = [i]
+        L.mm_dtype_size.restype = sz
+        L.mm_config_supported.argtypes = [cfgp]
+        L.mm_kernel_name.argtypes = [cfgp, u, u, u]
+        L.mm_kernel_name.restype = ctypes.c_char_p
+        L.mm_last_error.restype = ctypes.c_char_p
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise MMError(f"mm_gemm status {rc}: {lib().mm_last_error().decode()}")
+
+
+def make_config(dtype="float", map_op="Multiply", reduce_op="Add", path=PATH_AUTO, transposed_a=False):
+    return Config(DTYPES[dtype], OPS[map_op], OPS[reduce_op], path, int(transposed_a))
+
+
+def device_count():
+    n = ctypes.c_int(0)
+    _check(lib().mm_init(ctypes.byref(n)))
+    return n.value
+
+
+def kernel_name(cfg, n, k, m):
+    return lib().mm_kernel_name(ctypes.byref(cfg), n, k, m).decode()
+
+
+_TORCH_DTYPES = None
+
+
+def torch_dtype(dtype):
+    global _TORCH_DTYPES
+    import torch
+    if _TORCH_DTYPES is None:
+        _TORCH_DTYPES = {"float": torch.float32, "double": torch.float64, "half": torch.float16,
+                         "int8_t": torch.int8, "uint8_t": torch.uint8, "int16_t": torch.int16,
+                         "uint16_t": torch.uint16, "int": torch.int32, "unsigned": torch.uint32,
+                         "long": torch.int64, "unsigned long": torch.uint64}
+    return _TORCH_DTYPES[dtype]
+
+
+def matmul(a, b, dtype="float", map_op="Multiply", reduce_op="Add", path=PATH_AUTO, transposed_a=False,
+           out=None):
+    """C = A (map, reduce) B on the current CUDA(HIP) device and torch's current stream.
+    a: (N, K) -- or (K, N) with transposed_a -- b: (K, M); contiguous device tensors whose torch
+    dtype matches `dtype`.  Asynchronous, like any torch op."""
+    import torch
+    if not (a.is_cuda and b.is_cuda):
+        raise MMError("matmul needs device tensors: there is no CPU path")
+    assert a.is_contiguous() and b.is_contiguous()
+    tdt = torch_dtype(dtype)
+    assert a.dtype == tdt and b.dtype == tdt, (a.dtype, b.dtype, tdt)
+    k, m = b.shape
+    n = a.shape[1] if transposed_a else a.shape[0]
+    assert (a.shape[0] if transposed_a else a.shape[1]) == k
+    if out is None:
+        out = torch.empty((n, m), dtype=tdt, device=a.device)
+    cfg = make_config(dtype, map_op, reduce_op, path, transposed_a)
+    stream = torch.cuda.current_stream(a.device).cuda_stream
+    _check(lib().mm_gemm_enqueue(ctypes.c_void_p(stream), ctypes.byref(cfg), a.data_ptr(), b.data_ptr(),
+                                 out.data_ptr(), n, k, m))
+    return out
+
+
+def matmul_host(a, b, dtype="float", map_op="Multiply", reduce_op="Add", path=PATH_AUTO, devices=1):
+    """numpy in, numpy out, through mm_gemm_multi_device (rows of C split over `devices` GPUs).
+    Returns (C, kernel_seconds)."""
+    import numpy as np
+    a = np.ascontiguousarray(a)
+    b = np.ascontiguousarray(b)
+    n, k = a.shape
+    m = b.shape[1]
+    c = np.empty((n, m), dtype=a.dtype)
+    cfg = make_config(dtype, map_op, reduce_op, path)
+    t = ctypes.c_double(0)
+    _check(lib().mm_gemm_multi_device(devices, ctypes.byref(cfg), a.ctypes.data, b.ctypes.data, c.ctypes.data,
+                                      n, k, m, ctypes.byref(t)))
+    return c, t.value
+
+
+def matmul_capi(a, b, dtype="float", map_op="Multiply", reduce_op="Add", path=PATH_AUTO, transposed_a=False,
+                device=0):
+    """numpy in, numpy out, through the split-phase C ABI exactly as host/RunHardware.cpp drives the
+    reference: mm_alloc x3, mm_copy_to_device x2, mm_gemm_launch (blocking, HIP-event timed),
+    mm_copy_to_host.  Returns (C, kernel_seconds)."""
+    import numpy as np
+    L = lib()
+    a = np.ascontiguousarray(a)
+    b = np.ascontiguousarray(b)
+    k, m = b.shape
+    n = a.shape[1] if transposed_a else a.shape[0]
+    c = np.empty((n, m), dtype=a.dtype)
+    cfg = make_config(dtype, map_op, reduce_op, path, transposed_a)
+    ptrs = [ctypes.c_void_p() for _ in range(3)]
+    t = ctypes.c_double(0)
+    try:
+        for p, arr in zip(ptrs, (a, b, c)):
+            _check(L.mm_alloc(device, arr.nbytes, ctypes.byref(p)))
+        _check(L.mm_copy_to_device(device, ptrs[0], a.ctypes.data, a.nbytes))
+        _check(L.mm_copy_to_device(device, ptrs[1], b.ctypes.data, b.nbytes))
+        _check(L.mm_gemm_launch(device, ctypes.byref(cfg), ptrs[0], ptrs[1], ptrs[2], n, k, m, ctypes.byref(t)))
+        _check(L.mm_copy_to_host(device, c.ctypes.data, ptrs[2], c.nbytes))
+    finally:
+        for p in ptrs:
+            if p.value:
+                L.mm_free(device, p)
+    return c, t.value

@@ -1,0 +1,336 @@
+// C ABI of libmm_gemm_amd.so (declared in include/mm_gemm.h): device management, dispatch to
+// the gfx950 kernel families, the timed blocking launch that replaces hlslib's
+// Kernel::ExecuteTask() (host/RunHardware.cpp:161-162), the N-split multi-device driver and the
+// reference's own entry point MatrixMultiplicationKernel (kernel/Top.cpp:6-18).
+// There is no CPU compute path in this file or anywhere in this library.
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "mm_common.h"
+
+namespace {
+
+thread_local char g_error[512] = "";
+
+int fail(int code, const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_error, sizeof(g_error), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+int hip_fail(hipError_t e, const char *what) {
+  return fail(e == hipErrorNoDevice || e == hipErrorInvalidDevice ? MM_ERR_NO_DEVICE : MM_ERR_HIP,
+              "%s: %s (%d)", what, hipGetErrorString(e), (int)e);
+}
+
+#define MM_HIP(call)                                   \
+  do {                                                 \
+    hipError_t e_ = (call);                            \
+    if (e_ != hipSuccess) return hip_fail(e_, #call);  \
+  } while (0)
+
+int g_device_count = -1;  // -1: not initialised
+mm_config_t g_default_cfg = {MM_DTYPE_F32, MM_OP_MULTIPLY, MM_OP_ADD, MM_PATH_AUTO, MM_A_ROW_MAJOR};
+
+int ensure_init() {
+  if (g_device_count >= 0) return g_device_count > 0 ? MM_OK : fail(MM_ERR_NO_DEVICE, "no gfx950 device");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) {
+    g_device_count = 0;
+    return fail(MM_ERR_NO_DEVICE, "hipGetDeviceCount: %s; this library needs an MI355X (gfx950), there is no CPU fallback",
+                e == hipSuccess ? "0 devices" : hipGetErrorString(e));
+  }
+  for (int d = 0; d < n; ++d) {
+    hipDeviceProp_t prop;
+    MM_HIP(hipGetDeviceProperties(&prop, d));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+      g_device_count = 0;
+      return fail(MM_ERR_NO_DEVICE, "device %d is %s; the kernels in this library are built for gfx950 only", d,
+                  prop.gcnArchName);
+    }
+  }
+  g_device_count = n;
+  return MM_OK;
+}
+
+int check_device(int device) {
+  int rc = ensure_init();
+  if (rc) return rc;
+  if (device < 0 || device >= g_device_count)
+    return fail(MM_ERR_BAD_ARGUMENT, "device %d out of range [0, %d)", device, g_device_count);
+  return MM_OK;
+}
+
+bool valid_cfg(const mm_config_t *cfg) {
+  return cfg && cfg->dtype >= MM_DTYPE_F32 && cfg->dtype <= MM_DTYPE_U64 && cfg->map_op >= MM_OP_ADD &&
+         cfg->map_op <= MM_OP_MAX && cfg->reduce_op >= MM_OP_ADD && cfg->reduce_op <= MM_OP_MAX &&
+         (cfg->path == MM_PATH_AUTO || cfg->path == MM_PATH_ORDERED) &&
+         (cfg->layout_a == MM_A_ROW_MAJOR || cfg->layout_a == MM_A_TRANSPOSED);
+}
+
+int f32_variant() {
+  static int cached = -2;
+  const char *e = getenv("MM_F32_VARIANT");  // tuning hook for bench sweeps; re-read each call
+  if (e && *e) return atoi(e);
+  if (cached == -2) cached = 0;
+  return cached;
+}
+
+enum Family { FAM_ORDERED, FAM_VALU_TILE, FAM_MFMA_F32, FAM_MFMA_F64, FAM_MFMA_F16 };
+
+Family choose(const mm_config_t &cfg, const mm::Problem &p) {
+  if (cfg.path == MM_PATH_ORDERED) return FAM_ORDERED;
+  const bool mul_add = cfg.map_op == MM_OP_MULTIPLY && cfg.reduce_op == MM_OP_ADD;
+  if (mul_add && cfg.dtype == MM_DTYPE_F32 && mm::mfma_f32_serves(p)) return FAM_MFMA_F32;
+  if (mul_add && cfg.dtype == MM_DTYPE_F64 && mm::mfma_f64_serves(p)) return FAM_MFMA_F64;
+  if (mul_add && cfg.dtype == MM_DTYPE_F16 && mm::mfma_f16_serves(p)) return FAM_MFMA_F16;
+  return FAM_VALU_TILE;
+}
+
+int dispatch(hipStream_t s, const mm_config_t &cfg, const mm::Problem &p) {
+  if (p.n == 0 || p.m == 0) return MM_OK;  // nothing to write
+  int e;
+  switch (choose(cfg, p)) {
+    case FAM_MFMA_F32: e = mm::launch_mfma_f32(s, p, f32_variant()); break;
+    case FAM_MFMA_F64: e = mm::launch_mfma_f64(s, p); break;
+    case FAM_MFMA_F16: e = mm::launch_mfma_f16(s, p); break;
+    case FAM_VALU_TILE:
+      e = mm::launch_valu_tile(s, cfg, p);
+      if (e == mm::kErrNotSupported) e = mm::launch_ordered(s, cfg, p);  // still the GPU
+      break;
+    default: e = mm::launch_ordered(s, cfg, p); break;
+  }
+  if (e == mm::kErrNotSupported)
+    return fail(MM_ERR_UNSUPPORTED, "configuration (dtype %d, map %d, reduce %d) is not compiled into this library",
+                (int)cfg.dtype, (int)cfg.map_op, (int)cfg.reduce_op);
+  if (e != 0) return hip_fail((hipError_t)e, "kernel launch");
+  return MM_OK;
+}
+
+int check_problem(const mm_config_t *cfg, const void *a, const void *b, void *c, unsigned n, unsigned k, unsigned m) {
+  if (!valid_cfg(cfg)) return fail(MM_ERR_BAD_ARGUMENT, "invalid mm_config_t");
+  if (k == 0) return fail(MM_ERR_BAD_ARGUMENT, "size_k must be positive");
+  if (n && m && (!a || !b || !c)) return fail(MM_ERR_BAD_ARGUMENT, "null matrix pointer");
+  return MM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *mm_last_error(void) { return g_error; }
+
+size_t mm_dtype_size(mm_dtype_t dtype) {
+  static const size_t sz[] = {4, 8, 2, 1, 1, 2, 2, 4, 4, 8, 8};
+  return (dtype >= MM_DTYPE_F32 && dtype <= MM_DTYPE_U64) ? sz[dtype] : 0;
+}
+
+int mm_init(int *device_count) {
+  int rc = ensure_init();
+  if (device_count) *device_count = g_device_count > 0 ? g_device_count : 0;
+  return rc;
+}
+
+int mm_alloc(int device, size_t bytes, void **device_ptr) {
+  if (!device_ptr) return fail(MM_ERR_BAD_ARGUMENT, "device_ptr is null");
+  int rc = check_device(device);
+  if (rc) return rc;
+  MM_HIP(hipSetDevice(device));
+  MM_HIP(hipMalloc(device_ptr, bytes ? bytes : 1));
+  return MM_OK;
+}
+
+int mm_free(int device, void *device_ptr) {
+  int rc = check_device(device);
+  if (rc) return rc;
+  MM_HIP(hipSetDevice(device));
+  MM_HIP(hipFree(device_ptr));
+  return MM_OK;
+}
+
+int mm_copy_to_device(int device, void *dst, const void *src, size_t bytes) {
+  int rc = check_device(device);
+  if (rc) return rc;
+  if (bytes && (!dst || !src)) return fail(MM_ERR_BAD_ARGUMENT, "null pointer in copy");
+  MM_HIP(hipSetDevice(device));
+  MM_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+  return MM_OK;
+}
+
+int mm_copy_to_host(int device, void *dst, const void *src, size_t bytes) {
+  int rc = check_device(device);
+  if (rc) return rc;
+  if (bytes && (!dst || !src)) return fail(MM_ERR_BAD_ARGUMENT, "null pointer in copy");
+  MM_HIP(hipSetDevice(device));
+  MM_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+  return MM_OK;
+}
+
+int mm_fill_device(int device, mm_dtype_t dtype, void *ptr, size_t elements, unsigned long long seed) {
+  int rc = check_device(device);
+  if (rc) return rc;
+  if (!mm_dtype_size(dtype) || (elements && !ptr)) return fail(MM_ERR_BAD_ARGUMENT, "bad fill arguments");
+  MM_HIP(hipSetDevice(device));
+  int e = mm::launch_fill(nullptr, dtype, ptr, elements, seed);
+  if (e) return hip_fail((hipError_t)e, "fill launch");
+  MM_HIP(hipDeviceSynchronize());
+  return MM_OK;
+}
+
+int mm_gemm_enqueue(void *hip_stream, const mm_config_t *cfg, const void *a, const void *b, void *c, unsigned n,
+                    unsigned k, unsigned m) {
+  int rc = ensure_init();
+  if (rc) return rc;
+  rc = check_problem(cfg, a, b, c, n, k, m);
+  if (rc) return rc;
+  mm::Problem p{a, b, c, n, k, m, cfg->layout_a == MM_A_TRANSPOSED};
+  return dispatch((hipStream_t)hip_stream, *cfg, p);
+}
+
+int mm_gemm_launch(int device, const mm_config_t *cfg, const void *a, const void *b, void *c, unsigned n, unsigned k,
+                   unsigned m, double *elapsed_seconds) {
+  int rc = check_device(device);
+  if (rc) return rc;
+  rc = check_problem(cfg, a, b, c, n, k, m);
+  if (rc) return rc;
+  MM_HIP(hipSetDevice(device));
+  hipEvent_t start, stop;
+  MM_HIP(hipEventCreate(&start));
+  MM_HIP(hipEventCreate(&stop));
+  mm::Problem p{a, b, c, n, k, m, cfg->layout_a == MM_A_TRANSPOSED};
+  MM_HIP(hipEventRecord(start, nullptr));
+  rc = dispatch(nullptr, *cfg, p);
+  if (rc == MM_OK) {
+    hipError_t e = hipEventRecord(stop, nullptr);
+    if (e == hipSuccess) e = hipEventSynchronize(stop);
+    if (e != hipSuccess) rc = hip_fail(e, "kernel execution");
+  }
+  if (rc == MM_OK && elapsed_seconds) {
+    float ms = 0.f;
+    hipError_t e = hipEventElapsedTime(&ms, start, stop);
+    if (e != hipSuccess) rc = hip_fail(e, "hipEventElapsedTime");
+    *elapsed_seconds = 1e-3 * (double)ms;
+  }
+  (void)hipEventDestroy(start);
+  (void)hipEventDestroy(stop);
+  return rc;
+}
+
+int mm_gemm_multi_device(int device_count, const mm_config_t *cfg, const void *a_host, const void *b_host,
+                         void *c_host, unsigned n, unsigned k, unsigned m, double *elapsed_seconds) {
+  int rc = ensure_init();
+  if (rc) return rc;
+  rc = check_problem(cfg, a_host, b_host, c_host, n, k, m);
+  if (rc) return rc;
+  if (device_count < 1 || device_count > g_device_count)
+    return fail(MM_ERR_BAD_ARGUMENT, "device_count %d not in [1, %d]", device_count, g_device_count);
+  if (cfg->layout_a == MM_A_TRANSPOSED)
+    return fail(MM_ERR_UNSUPPORTED, "row split of a K x N (transposed) A is not contiguous; use one device");
+  const size_t es = mm_dtype_size(cfg->dtype);
+  const unsigned slab = (n + device_count - 1) / device_count;  // rows per device
+  struct Dev { void *a = nullptr, *b = nullptr, *c = nullptr; unsigned row0 = 0, rows = 0; hipStream_t s = nullptr; };
+  std::vector<Dev> devs(device_count);
+  auto cleanup = [&]() {
+    for (int g = 0; g < device_count; ++g) {
+      (void)hipSetDevice(g);
+      if (devs[g].a) (void)hipFree(devs[g].a);
+      if (devs[g].b) (void)hipFree(devs[g].b);
+      if (devs[g].c) (void)hipFree(devs[g].c);
+      if (devs[g].s) (void)hipStreamDestroy(devs[g].s);
+    }
+  };
+#define MM_HIP_MD(call)                                                  \
+  do {                                                                   \
+    hipError_t e_ = (call);                                              \
+    if (e_ != hipSuccess) { cleanup(); return hip_fail(e_, #call); }     \
+  } while (0)
+  // independent row slabs: device g owns C[row0 : row0+rows, :] = A[row0 : row0+rows, :] . B
+  for (int g = 0; g < device_count; ++g) {
+    Dev &d = devs[g];
+    d.row0 = (unsigned)std::min<size_t>((size_t)g * slab, n);
+    d.rows = std::min(slab, n - d.row0);
+    MM_HIP_MD(hipSetDevice(g));
+    MM_HIP_MD(hipStreamCreateWithFlags(&d.s, hipStreamNonBlocking));
+    MM_HIP_MD(hipMalloc(&d.b, (size_t)k * m * es));
+    MM_HIP_MD(hipMemcpyAsync(d.b, b_host, (size_t)k * m * es, hipMemcpyHostToDevice, d.s));
+    if (d.rows) {
+      MM_HIP_MD(hipMalloc(&d.a, (size_t)d.rows * k * es));
+      MM_HIP_MD(hipMalloc(&d.c, (size_t)d.rows * m * es));
+      MM_HIP_MD(hipMemcpyAsync(d.a, (const char *)a_host + (size_t)d.row0 * k * es, (size_t)d.rows * k * es,
+                               hipMemcpyHostToDevice, d.s));
+    }
+  }
+  for (int g = 0; g < device_count; ++g) { MM_HIP_MD(hipSetDevice(g)); MM_HIP_MD(hipStreamSynchronize(devs[g].s)); }
+  // timed region: common start -> every device complete (copies excluded, as RunHardware.cpp does)
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int g = 0; g < device_count; ++g) {
+    Dev &d = devs[g];
+    if (!d.rows) continue;
+    MM_HIP_MD(hipSetDevice(g));
+    mm::Problem p{d.a, d.b, d.c, d.rows, k, m, false};
+    rc = dispatch(d.s, *cfg, p);
+    if (rc) { cleanup(); return rc; }
+  }
+  for (int g = 0; g < device_count; ++g) { MM_HIP_MD(hipSetDevice(g)); MM_HIP_MD(hipStreamSynchronize(devs[g].s)); }
+  const auto t1 = std::chrono::steady_clock::now();
+  if (elapsed_seconds) *elapsed_seconds = std::chrono::duration<double>(t1 - t0).count();
+  for (int g = 0; g < device_count; ++g) {
+    Dev &d = devs[g];
+    if (!d.rows) continue;
+    MM_HIP_MD(hipSetDevice(g));
+    MM_HIP_MD(hipMemcpy((char *)c_host + (size_t)d.row0 * m * es, d.c, (size_t)d.rows * m * es, hipMemcpyDeviceToHost));
+  }
+#undef MM_HIP_MD
+  cleanup();
+  return MM_OK;
+}
+
+int mm_set_default_config(const mm_config_t *cfg) {
+  if (!valid_cfg(cfg)) return fail(MM_ERR_BAD_ARGUMENT, "invalid mm_config_t");
+  g_default_cfg = *cfg;
+  return MM_OK;
+}
+
+void MatrixMultiplicationKernel(const void *a, const void *b, void *c, unsigned n, unsigned k, unsigned m) {
+  const mm_config_t cfg = g_default_cfg;
+  const size_t es = mm_dtype_size(cfg.dtype);
+  void *ad = nullptr, *bd = nullptr, *cd = nullptr;
+  int rc = mm_alloc(0, (size_t)n * k * es, &ad);
+  if (!rc) rc = mm_alloc(0, (size_t)k * m * es, &bd);
+  if (!rc) rc = mm_alloc(0, (size_t)n * m * es, &cd);
+  if (!rc) rc = mm_copy_to_device(0, ad, a, (size_t)n * k * es);
+  if (!rc) rc = mm_copy_to_device(0, bd, b, (size_t)k * m * es);
+  if (!rc) rc = mm_gemm_launch(0, &cfg, ad, bd, cd, n, k, m, nullptr);
+  if (!rc) rc = mm_copy_to_host(0, c, cd, (size_t)n * m * es);
+  if (ad) mm_free(0, ad);
+  if (bd) mm_free(0, bd);
+  if (cd) mm_free(0, cd);
+  if (rc) {
+    fprintf(stderr, "MatrixMultiplicationKernel failed: %s\n", mm_last_error());
+    abort();  // the reference's symbol returns void; failing silently would fake a result
+  }
+}
+
+int mm_config_supported(const mm_config_t *cfg) { return valid_cfg(cfg) ? 1 : 0; }
+
+const char *mm_kernel_name(const mm_config_t *cfg, unsigned n, unsigned k, unsigned m) {
+  if (!valid_cfg(cfg)) return "invalid";
+  mm::Problem p{nullptr, nullptr, nullptr, n, k, m, cfg->layout_a == MM_A_TRANSPOSED};
+  switch (choose(*cfg, p)) {
+    case FAM_MFMA_F32: return mm::mfma_f32_name(f32_variant());
+    case FAM_MFMA_F64: return "mfma_f64";
+    case FAM_MFMA_F16: return "mfma_f16";
+    case FAM_VALU_TILE: return "valu_tile";
+    default: return "ordered";
+  }
+}
+
+}  // extern "C"

@@ -1,0 +1,105 @@
+// Shared device-side vocabulary of the gfx950 kernels: element types, the (map, reduce)
+// operator functors and launch descriptors.  Mirrors what the reference gets from
+// include/Config.h.in:15,34-35 (Data_t, OperatorMap, OperatorReduce) and from
+// hlslib::op::{Add,Multiply,And,Min,Max} (third-party header, absent from the reference tree;
+// semantics: Apply(a,b) and identity(), used at kernel/Compute.cpp:129,133 and
+// include/Utility.h:29,37).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mm_gemm.h"
+
+namespace mm {
+
+using half_t = _Float16;
+
+// ---- operators -------------------------------------------------------------------------------
+template <typename T> struct Limits;
+template <> struct Limits<float> {
+  __host__ __device__ static constexpr float max() { return 3.40282346638528859812e+38f; }
+  __host__ __device__ static constexpr float lowest() { return -3.40282346638528859812e+38f; }
+};
+template <> struct Limits<double> {
+  __host__ __device__ static constexpr double max() { return 1.79769313486231570815e+308; }
+  __host__ __device__ static constexpr double lowest() { return -1.79769313486231570815e+308; }
+};
+template <> struct Limits<half_t> {
+  __host__ __device__ static constexpr half_t max() { return (half_t)65504.0f; }
+  __host__ __device__ static constexpr half_t lowest() { return (half_t)-65504.0f; }
+};
+#define MM_INT_LIMITS(T, LO, HI)                                       \
+  template <> struct Limits<T> {                                       \
+    __host__ __device__ static constexpr T max() { return HI; }        \
+    __host__ __device__ static constexpr T lowest() { return LO; }     \
+  };
+MM_INT_LIMITS(int8_t, INT8_MIN, INT8_MAX)
+MM_INT_LIMITS(uint8_t, 0, UINT8_MAX)
+MM_INT_LIMITS(int16_t, INT16_MIN, INT16_MAX)
+MM_INT_LIMITS(uint16_t, 0, UINT16_MAX)
+MM_INT_LIMITS(int32_t, INT32_MIN, INT32_MAX)
+MM_INT_LIMITS(uint32_t, 0, UINT32_MAX)
+MM_INT_LIMITS(int64_t, INT64_MIN, INT64_MAX)
+MM_INT_LIMITS(uint64_t, 0, UINT64_MAX)
+#undef MM_INT_LIMITS
+
+template <int OP, typename T> struct Op;
+template <typename T> struct Op<MM_OP_ADD, T> {
+  __device__ static __forceinline__ T apply(T a, T b) { return (T)(a + b); }
+  __host__ __device__ static constexpr T identity() { return (T)0; }
+};
+template <typename T> struct Op<MM_OP_MULTIPLY, T> {
+  __device__ static __forceinline__ T apply(T a, T b) { return (T)(a * b); }
+  __host__ __device__ static constexpr T identity() { return (T)1; }
+};
+template <typename T> struct Op<MM_OP_AND, T> {
+  __device__ static __forceinline__ T apply(T a, T b) { return (T)((a != (T)0) && (b != (T)0)); }
+  __host__ __device__ static constexpr T identity() { return (T)1; }
+};
+template <typename T> struct Op<MM_OP_MIN, T> {
+  __device__ static __forceinline__ T apply(T a, T b) { return b < a ? b : a; }  // std::min
+  __host__ __device__ static constexpr T identity() { return Limits<T>::max(); }
+};
+template <typename T> struct Op<MM_OP_MAX, T> {
+  __device__ static __forceinline__ T apply(T a, T b) { return a < b ? b : a; }  // std::max
+  __host__ __device__ static constexpr T identity() { return Limits<T>::lowest(); }
+};
+
+// ---- problem descriptor handed to every kernel launcher --------------------------------------
+struct Problem {
+  const void *a;   // N x K row-major (or K x N when a_transposed)
+  const void *b;   // K x M row-major
+  void *c;         // N x M row-major, pure output
+  unsigned n, k, m;
+  bool a_transposed;
+};
+
+// Launchers (one translation unit each).  Return hipError_t as int; hipErrorNotSupported (801)
+// means "this family does not serve this (config, shape)".
+int launch_ordered(hipStream_t s, const mm_config_t &cfg, const Problem &p);
+int launch_valu_tile(hipStream_t s, const mm_config_t &cfg, const Problem &p);
+int launch_mfma_f32(hipStream_t s, const Problem &p, int variant);
+int launch_mfma_f64(hipStream_t s, const Problem &p);
+int launch_mfma_f16(hipStream_t s, const Problem &p);
+bool mfma_f32_serves(const Problem &p);
+bool mfma_f64_serves(const Problem &p);
+bool mfma_f16_serves(const Problem &p);
+const char *mfma_f32_name(int variant);
+int mfma_f32_num_variants();
+int launch_fill(hipStream_t s, mm_dtype_t dtype, void *ptr, size_t elements, unsigned long long seed);
+
+constexpr int kErrNotSupported = 801;  // hipErrorNotSupported
+
+// XCD-aware remap of a 1-D workgroup id: the dispatcher places workgroup b on XCD b % 8
+// (observed, used for speed only); give every XCD one contiguous chunk of the tile order so that
+// tiles sharing A row-panels / B column-panels meet in the same private L2.  Bijective for any
+// grid size.
+__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg) {
+  constexpr unsigned kXcds = 8;
+  const unsigned q = nwg / kXcds, r = nwg % kXcds;
+  const unsigned xcd = bid % kXcds, slot = bid / kXcds;
+  const unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + slot;
+}
+
+}  // namespace mm

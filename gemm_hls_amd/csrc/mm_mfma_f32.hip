@@ -1,0 +1,333 @@
+// fp32 (Multiply, Add) fast path for gfx950: C[N x M] = A[N x K] . B[K x M], all row-major.
+//
+// This is the MI355X counterpart of the reference's ProcessingElement chain + ReadA/TransposeA/
+// ReadB/FeedB/WriteC streaming (kernel/Compute.cpp:11-231, kernel/Memory.cpp:106-438): an output
+// tile stays resident on chip for the whole K loop ("we do not tile K further",
+// kernel/Compute.cpp:58-60) while K-slabs of the A row-panel and B column-panel stream past it.
+// Here the resident tile lives in the accumulation registers of the wavefronts of one workgroup
+// and the slabs are DMA'd HBM/L2 -> LDS (global_load_lds, 16 B per lane, no VGPR round trip).
+//
+// Geometry (template parameters):
+//   workgroup = WM x WN wavefronts; each wavefront owns a (TM*32) x 128 block of C as TM x 4
+//   v_mfma_f32_32x32x2_f32 accumulators; workgroup tile BM x BN = (WM*TM*32) x (WN*128);
+//   K is consumed in slabs of BK floats through an NS-deep LDS ring.
+//
+// LDS images (both written lane-linearly by the DMA, so any permutation is applied to the
+// per-lane SOURCE address):
+//   A slab: [BM rows][BK] floats, a row = BK/4 16-byte chunks, chunk index XOR-swizzled with
+//           (row >> log2(16/CPR)) so that the 16 lanes of each ds_read_b128 service group hit 16
+//           distinct 16-B slots of the 256-B bank row (conflict-free, checked by enumeration in
+//           tests/test_layouts.py).
+//   B slab: [BK][BN] floats, untouched (a k-row is 1 KiB == one wave-level DMA instruction).
+//
+// Fragment trick: the MFMA wants A[i][k] / B[k][j] with (i or j) = lane&31 and k = lane>>5.
+//   A: lane reads 16 B = A[row = lane&31][4 consecutive k, at k-offset 4*(lane>>5)] -> the 4
+//      dwords feed 4 successive MFMAs whose k-pairs are (p, p+4), p = 0..3, of an 8-deep k-group.
+//   B: lane reads 16 B = B[k = p + 4*(lane>>5)][4 consecutive columns 4*(lane&31)..+3] -> the 4
+//      dwords feed the 4 column-accumulators, accumulator t holding columns 4*j+t.
+//   So per 8 k's a wavefront issues TM + 4 ds_read_b128 for 16*TM MFMAs, and in the epilogue a
+//   lane owns 4 CONSECUTIVE columns of a row -> one 16-byte store, 512 contiguous bytes per
+//   half-wave.
+// Accumulation order per output element: k-groups ascending, inside a group k = 0,4,1,5,2,6,3,7.
+// Each MFMA is an exact-f32 fused multiply-add chain (one rounding per product).
+//
+// Two-level accumulation (TWO_LEVEL): every KC k-slabs the MFMA accumulators are added into a
+// second register set and restarted from zero.  A single 16384-long f32 chain of positive
+// products drifts to ~1e-5 relative in the worst element; with 512-deep chunks
+// the worst case stays < 1e-6, inside BASELINE.json's 1e-5 bar with margin.
+//
+// Edges: N arbitrary (row indices clamped for loads, stores predicated); M % 4 == 0 (column
+// chunks clamped / predicated); K % 8 == 0 (a partial last slab is consumed in 8-deep groups;
+// the DMA of its unused part is clamped to valid addresses and never read).  Everything else is
+// served by the predicated kernels (mm_valu_tile / mm_ordered).
+#include "mm_common.h"
+
+namespace mm {
+namespace {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+typedef const __attribute__((address_space(1))) void *gptr_t;
+typedef __attribute__((address_space(3))) void *lptr_t;
+
+template <int TM_, int WM_, int WN_, int BK_, int NS_, bool TWO_LEVEL_, int KC_>
+struct Geo {
+  static constexpr int TM = TM_, WM = WM_, WN = WN_, BK = BK_, NS = NS_, KC = KC_;
+  static constexpr bool TWO_LEVEL = TWO_LEVEL_;
+  static constexpr int TN = 4;                       // 4 accumulators x 32 = 128 columns per wave
+  static constexpr int NW = WM * WN;                 // wavefronts per workgroup
+  static constexpr int THREADS = NW * 64;
+  static constexpr int BM = WM * TM * 32, BN = WN * 128;
+  static constexpr int CPR = BK / 4;                 // 16-B chunks per A row
+  static constexpr int SWZ_SHIFT = (CPR == 4) ? 2 : 1;
+  static constexpr int A_BYTES = BM * BK * 4, B_BYTES = BK * BN * 4;
+  static constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
+  static constexpr int LDS_BYTES = NS * STAGE_BYTES;
+  static constexpr int NA = A_BYTES / 1024, NB = B_BYTES / 1024;  // wave-level DMA instructions
+  static constexpr int LA = NA / NW, LB = NB / NW;                // ... per wavefront
+  static constexpr int KG = BK / 8;                               // 8-deep k-groups per slab
+  static_assert(BK == 16 || BK == 32, "BK");
+  static_assert(NA % NW == 0 && NB % NW == 0, "DMA instructions must split evenly over waves");
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+};
+
+template <typename G>
+__global__ __launch_bounds__(G::THREADS) void mfma_f32_kernel(const float *__restrict__ A,
+                                                              const float *__restrict__ B,
+                                                              float *__restrict__ C, unsigned N,
+                                                              unsigned K, unsigned M,
+                                                              unsigned tiles_n, unsigned tiles_m) {
+  constexpr int TM = G::TM, TN = G::TN, BK = G::BK, NS = G::NS, CPR = G::CPR;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const unsigned lane = threadIdx.x & 63u;
+  const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const unsigned wm = wave / G::WN, wn = wave % G::WN;
+  const unsigned lo = lane & 31u, hi = lane >> 5;
+
+  // ---- workgroup -> output tile: XCD-contiguous chunks, then bands of 8 tile-rows ----------
+  const unsigned nwg = tiles_n * tiles_m;
+  const unsigned lin = xcd_remap(blockIdx.x, nwg);
+  constexpr unsigned kBand = 8;
+  const unsigned band = lin / (kBand * tiles_m), within = lin % (kBand * tiles_m);
+  const unsigned rows_in_band = min(kBand, tiles_n - band * kBand);
+  const unsigned tile_row = band * kBand + within % rows_in_band;
+  const unsigned tile_col = within / rows_in_band;
+  const unsigned row0 = tile_row * G::BM, col0 = tile_col * G::BN;
+
+  // ---- per-lane DMA sources ----------------------------------------------------------------
+  // A instruction ja covers LDS 16-B slots [ja*64, ja*64+64): slot -> (row, physical chunk).
+  size_t a_row_off[G::LA];   // element offset of the (clamped) source row
+  unsigned a_kchunk[G::LA];  // logical k-chunk (x4 floats) this lane fetches
+#pragma unroll
+  for (int i = 0; i < G::LA; ++i) {
+    const unsigned slot = (wave + G::NW * i) * 64 + lane;
+    const unsigned row = slot / CPR, pc = slot % CPR;
+    a_kchunk[i] = pc ^ ((row >> G::SWZ_SHIFT) & (CPR - 1));
+    a_row_off[i] = (size_t)min(row0 + row, N - 1) * K;
+  }
+  unsigned b_krow[G::LB];
+  unsigned b_col[G::LB];
+#pragma unroll
+  for (int i = 0; i < G::LB; ++i) {
+    const unsigned slot = (wave + G::NW * i) * 64 + lane;
+    b_krow[i] = slot / (G::BN / 4);
+    b_col[i] = min(col0 + (slot % (G::BN / 4)) * 4, M - 4);
+  }
+
+  auto stage = [&](unsigned buf, unsigned k0) {
+    char *base = smem + buf * G::STAGE_BYTES;
+#pragma unroll
+    for (int i = 0; i < G::LA; ++i) {
+      const unsigned kk = min(k0 + a_kchunk[i] * 4, K - 4);
+      const float *src = A + a_row_off[i] + kk;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(base + (wave + G::NW * i) * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < G::LB; ++i) {
+      const unsigned kr = min(k0 + b_krow[i], K - 1);
+      const float *src = B + (size_t)kr * M + b_col[i];
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(base + G::A_BYTES + (wave + G::NW * i) * 1024), 16, 0, 0);
+    }
+  };
+
+  // ---- per-lane fragment addresses (bytes inside a stage) -------------------------------------
+  // A: row = wm*TM*32 + mi*32 + lo; chunk = (2*kg + hi) ^ swz(row) = (2*kg) ^ (hi ^ swz(lo))
+  const unsigned a_swz = hi ^ ((lo >> G::SWZ_SHIFT) & (CPR - 1));
+  const unsigned a_frag_base = (wm * TM * 32 + lo) * (BK * 4);
+  // B: k = kg*8 + p + 4*hi; col = wn*128 + 4*lo
+  const unsigned b_frag_base = G::A_BYTES + (4 * hi) * (G::BN * 4) + (wn * 128 + 4 * lo) * 4;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+    for (int t = 0; t < TN; ++t) acc[mi][t] = (f32x16)0.0f;
+  f32x16 master[G::TWO_LEVEL ? TM : 1][G::TWO_LEVEL ? TN : 1];
+  if (G::TWO_LEVEL) {
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+      for (int t = 0; t < TN; ++t) master[mi][t] = (f32x16)0.0f;
+  }
+
+  auto load_frags = [&](unsigned buf, int kg, f32x4 (&af)[TM], f32x4 (&bf)[4]) {
+    const char *base = smem + buf * G::STAGE_BYTES;
+    const unsigned achunk = ((unsigned)(2 * kg) ^ a_swz) * 16;
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi)
+      af[mi] = *(const f32x4 *)(base + a_frag_base + mi * 32 * (BK * 4) + achunk);
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+      bf[p] = *(const f32x4 *)(base + b_frag_base + (kg * 8 + p) * (G::BN * 4));
+  };
+
+  auto mfma_group = [&](const f32x4 (&af)[TM], const f32x4 (&bf)[4]) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+        for (int t = 0; t < TN; ++t)
+          acc[mi][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi][p], bf[p][t], acc[mi][t], 0, 0, 0);
+  };
+
+  const unsigned num_tiles = (K + BK - 1) / BK;   // slabs, the last one possibly partial
+  constexpr int L = G::LA + G::LB;                // DMA instructions per wavefront per slab
+
+  // ---- prologue: fill the whole ring (slabs 0..NS-1), wait for slab 0 ------------------------
+  // stage() clamps every source address, so staging a slab index past the end is harmless
+  // (it lands in a ring slot nobody reads again); this keeps the steady state branch-free and
+  // the vmcnt immediates constant.
+#pragma unroll
+  for (int s = 0; s < NS; ++s) stage(s, s * BK);
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 1) * L) : "memory");
+  __builtin_amdgcn_s_barrier();
+
+  f32x4 af0[TM], bf0[4], af1[TM], bf1[4];
+  load_frags(0, 0, af0, bf0);
+
+  // One full slab that HAS a successor.  8-deep k-groups, register double-buffered fragments
+  // (set 0 for even groups, set 1 for odd; KG is even so the alternation carries across slabs).
+  // The last group's MFMAs are issued after the barrier that publishes slab t+1 and after that
+  // slab's first fragment reads, so barrier skew and LDS latency hide under them.
+  auto slab = [&](unsigned t) {
+    const unsigned buf = t % NS;
+#pragma unroll
+    for (int kg = 0; kg < G::KG; ++kg) {
+      f32x4(&afc)[TM] = (kg & 1) ? af1 : af0;
+      f32x4(&bfc)[4] = (kg & 1) ? bf1 : bf0;
+      f32x4(&afn)[TM] = (kg & 1) ? af0 : af1;
+      f32x4(&bfn)[4] = (kg & 1) ? bf0 : bf1;
+      if (kg + 1 < G::KG) {
+        load_frags(buf, kg + 1, afn, bfn);
+      } else {
+        // Slab t+1 must have landed; slabs t+2 .. t+NS-1 may stay in flight across the barrier.
+        // This wave's LDS reads of slab t are all in registers (lgkmcnt(0)), so after the
+        // barrier its ring slot is free for slab t+NS.
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NS - 2) * L) : "memory");
+        __builtin_amdgcn_s_barrier();
+        stage(buf, (t + NS) * BK);
+        load_frags((t + 1) % NS, 0, afn, bfn);
+      }
+      mfma_group(afc, bfc);
+    }
+  };
+
+  const unsigned steady = num_tiles - 1;  // slabs 0 .. num_tiles-2 are full and have a successor
+  if (G::TWO_LEVEL) {
+    for (unsigned t0 = 0; t0 < steady; t0 += G::KC) {
+      const unsigned tend = min(t0 + (unsigned)G::KC, steady);
+      for (unsigned t = t0; t < tend; ++t) slab(t);
+#pragma unroll
+      for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+        for (int tt = 0; tt < TN; ++tt) {
+          master[mi][tt] += acc[mi][tt];
+          acc[mi][tt] = (f32x16)0.0f;
+        }
+    }
+  } else {
+    for (unsigned t = 0; t < steady; ++t) slab(t);
+  }
+
+  // ---- last slab (full or partial): plain group loop, nothing left to prefetch --------------
+  {
+    const unsigned t = num_tiles - 1;
+    const int groups = (int)((K - t * BK) / 8);
+    for (int kg = 0; kg < groups; ++kg) {
+      load_frags(t % NS, kg, af0, bf0);
+      mfma_group(af0, bf0);
+    }
+  }
+
+  // Trailing (clamped, never read) ring refills may still be in flight: drain them before this
+  // wave can retire and its workgroup's LDS allocation can be handed to another workgroup.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  // ---- epilogue: lane owns 4 consecutive columns of 16 rows per accumulator row-block --------
+  const unsigned ccol = col0 + wn * 128 + 4 * lo;
+  if (ccol < M) {
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const unsigned row = row0 + wm * TM * 32 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        if (row < N) {
+          f32x4 v;
+#pragma unroll
+          for (int tt = 0; tt < TN; ++tt) {
+            float x = acc[mi][tt][r];
+            if (G::TWO_LEVEL) x += master[mi][tt][r];
+            v[tt] = x;
+          }
+          *(f32x4 *)(C + (size_t)row * M + ccol) = v;
+        }
+      }
+    }
+  }
+}
+
+template <typename G>
+int launch_geo(hipStream_t s, const Problem &p) {
+  const unsigned tiles_n = (p.n + G::BM - 1) / G::BM, tiles_m = (p.m + G::BN - 1) / G::BN;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void *)mfma_f32_kernel<G>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((mfma_f32_kernel<G>), dim3(tiles_n * tiles_m), dim3(G::THREADS), G::LDS_BYTES, s,
+                     (const float *)p.a, (const float *)p.b, (float *)p.c, p.n, p.k, p.m, tiles_n, tiles_m);
+  return (int)hipGetLastError();
+}
+
+//                TM WM WN BK NS two-level KC(slabs)
+using V0 = Geo<2, 2, 2, 32, 2, true, 16>;    // 128x256, 4 waves, 512-deep chunks
+using V1 = Geo<2, 2, 2, 32, 2, false, 1>;    // same, single chain
+using V2 = Geo<4, 2, 2, 16, 2, false, 1>;    // 256x256, 4 waves, 256 accumulators
+using V3 = Geo<2, 4, 2, 16, 2, false, 1>;    // 256x256, 8 waves (2 per SIMD)
+using V4 = Geo<2, 2, 2, 32, 3, true, 16>;    // V0 with a 3-deep ring and counted vmcnt
+using V5 = Geo<2, 2, 2, 16, 2, true, 32>;    // V0 with BK = 16
+using V6 = Geo<4, 2, 2, 16, 3, false, 1>;    // V2 with a 3-deep ring
+using V7 = Geo<1, 4, 2, 32, 2, true, 16>;    // 128x256, 8 waves, 32x128 per wave
+
+}  // namespace
+
+int mfma_f32_num_variants() { return 8; }
+
+const char *mfma_f32_name(int v) {
+  switch (v) {
+    case 0: return "mfma_f32_128x256x32_w4_2lvl";
+    case 1: return "mfma_f32_128x256x32_w4";
+    case 2: return "mfma_f32_256x256x16_w4";
+    case 3: return "mfma_f32_256x256x16_w8";
+    case 4: return "mfma_f32_128x256x32_w4_2lvl_ns3";
+    case 5: return "mfma_f32_128x256x16_w4_2lvl";
+    case 6: return "mfma_f32_256x256x16_w4_ns3";
+    case 7: return "mfma_f32_128x256x32_w8_2lvl";
+  }
+  return "?";
+}
+
+bool mfma_f32_serves(const Problem &p) {
+  return !p.a_transposed && p.n >= 1 && p.m >= 4 && p.k >= 8 && p.m % 4 == 0 && p.k % 8 == 0;
+}
+
+int launch_mfma_f32(hipStream_t s, const Problem &p, int variant) {
+  if (!mfma_f32_serves(p)) return kErrNotSupported;
+  switch (variant) {
+    case 0: return launch_geo<V0>(s, p);
+    case 1: return launch_geo<V1>(s, p);
+    case 2: return launch_geo<V2>(s, p);
+    case 3: return launch_geo<V3>(s, p);
+    case 4: return launch_geo<V4>(s, p);
+    case 5: return launch_geo<V5>(s, p);
+    case 6: return launch_geo<V6>(s, p);
+    case 7: return launch_geo<V7>(s, p);
+  }
+  return kErrNotSupported;
+}
+
+}  // namespace mm

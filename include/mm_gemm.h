@@ -1,0 +1,154 @@
+/*
+ * mm_gemm.h -- C ABI of the MI355X (gfx950) implementation of gemm_hls's hot path
+ *              C = A (map, reduce) B,  A: N x K, B: K x M, C: N x M, all row-major.
+ *
+ * Plain C, plain pointers and sizes.  One shared library (libmm_gemm_amd.so) exports all
+ * of it.  Every entry point names the reference interface it replaces (paths relative to the
+ * reference repository).  Unless stated otherwise a function returns 0 on success and a
+ * non-zero status otherwise, with a human-readable message available from mm_last_error();
+ * nothing throws across this boundary.  There is NO CPU fallback anywhere behind this ABI:
+ * without a usable gfx950 device every compute call fails with MM_ERR_NO_DEVICE.
+ */
+#ifndef MM_GEMM_H
+#define MM_GEMM_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Element type == the reference's build-time MM_DATA_TYPE / Data_t
+ * (CMakeLists.txt:17, include/Config.h.in:15; "half" and "uint8_t" special-cased at
+ * CMakeLists.txt:40-50). */
+typedef enum {
+  MM_DTYPE_F32 = 0, /* float          */
+  MM_DTYPE_F64 = 1, /* double         */
+  MM_DTYPE_F16 = 2, /* half (IEEE binary16; f32 accumulate, one rounding on store) */
+  MM_DTYPE_I8 = 3,  /* int8_t         */
+  MM_DTYPE_U8 = 4,  /* uint8_t        */
+  MM_DTYPE_I16 = 5, /* short          */
+  MM_DTYPE_U16 = 6, /* unsigned short */
+  MM_DTYPE_I32 = 7, /* int            */
+  MM_DTYPE_U32 = 8, /* unsigned       */
+  MM_DTYPE_I64 = 9, /* long           */
+  MM_DTYPE_U64 = 10 /* unsigned long  */
+} mm_dtype_t;
+
+/* == the reference's MM_MAP_OP / MM_REDUCE_OP, i.e. hlslib::op::<Name><Data_t>
+ * (CMakeLists.txt:33-34, include/Config.h.in:34-35; applied at kernel/Compute.cpp:129,133 and
+ * include/Utility.h:29,37).  identity(): Add 0, Multiply 1, And 1, Min max(), Max lowest(). */
+typedef enum {
+  MM_OP_ADD = 0,
+  MM_OP_MULTIPLY = 1,
+  MM_OP_AND = 2,
+  MM_OP_MIN = 3,
+  MM_OP_MAX = 4
+} mm_op_t;
+
+/* Which kernel family serves a launch.
+ *   MM_PATH_AUTO     the fast path for the configuration (MFMA for (Multiply,Add) on
+ *                    float/half/double, register-tiled VALU otherwise); == RunHardware "hw".
+ *   MM_PATH_ORDERED  the plain GPU kernel that evaluates every output as the reference's
+ *                    Naive does -- acc = identity; for k ascending: acc = Reduce(acc, Map(a,b)),
+ *                    multiply and add NOT fused -- bit-identical to include/Utility.h:18-42
+ *                    for every dtype; == RunHardware "hw_emu" (a slower, independently written
+ *                    execution of the same contract on the same device). */
+typedef enum { MM_PATH_AUTO = 0, MM_PATH_ORDERED = 1 } mm_path_t;
+
+/* Layout of A: row-major N x K (default) or K x N == the reference's MM_TRANSPOSED_A
+ * (CMakeLists.txt:30, include/Utility.h:31-35, kernel/Memory.cpp:205-261). */
+typedef enum { MM_A_ROW_MAJOR = 0, MM_A_TRANSPOSED = 1 } mm_layout_a_t;
+
+enum {
+  MM_OK = 0,
+  MM_ERR_NO_DEVICE = 1,   /* no gfx950 device / HIP runtime unusable            */
+  MM_ERR_BAD_ARGUMENT = 2,/* null pointer, unknown enum, device index out of range */
+  MM_ERR_UNSUPPORTED = 3, /* (dtype, map, reduce) not compiled into this library */
+  MM_ERR_HIP = 4          /* a HIP call failed; see mm_last_error()             */
+};
+
+typedef struct {
+  mm_dtype_t dtype;
+  mm_op_t map_op;
+  mm_op_t reduce_op;
+  mm_path_t path;
+  mm_layout_a_t layout_a;
+} mm_config_t;
+
+/* ---- device management: replaces hlslib::ocl::Context / MakeBuffer / CopyFromHost /
+ *      CopyToHost as used by host/RunHardware.cpp:116-145,187-190 ----------------------------- */
+
+/* hlslib::ocl::Context context; (RunHardware.cpp:116-117).  Reports the number of usable
+ * gfx950 devices. */
+int mm_init(int *device_count);
+
+/* context.MakeBuffer<...>(DDR bank, elements) (RunHardware.cpp:122-138).  The caller owns the
+ * returned device pointer and releases it with mm_free. */
+int mm_alloc(int device, size_t bytes, void **device_ptr);
+int mm_free(int device, void *device_ptr);
+
+/* buffer.CopyFromHost / CopyToHost (RunHardware.cpp:142-144,189).  Blocking. */
+int mm_copy_to_device(int device, void *device_dst, const void *host_src, size_t bytes);
+int mm_copy_to_host(int device, void *host_dst, const void *device_src, size_t bytes);
+
+/* Fill a device buffer with the reference's input distribution (uniform in [1,10], values
+ * drawn on the device, NOT the seed-5 host stream): for `verify off` timing runs, where the
+ * reference leaves its device buffers uninitialised (RunHardware.cpp:99,140). */
+int mm_fill_device(int device, mm_dtype_t dtype, void *device_ptr, size_t elements,
+                   unsigned long long seed);
+
+/* ---- the kernel: replaces program.MakeKernel("MatrixMultiplicationKernel", a, b, c, N, K, M)
+ *      + kernel.ExecuteTask() (RunHardware.cpp:148-162).  C is pure output (kernel/Top.cpp
+ *      never reads it).  Sizes follow the reference's contract (RunHardware.cpp:50-61): K and
+ *      M multiples of the 64-byte bus in elements; other sizes are served by a slower,
+ *      fully predicated kernel rather than rejected. ----------------------------------------- */
+
+/* Blocking launch on `device`; *elapsed_seconds (may be NULL) receives the kernel time
+ * measured with HIP events on the launch stream == ExecuteTask()'s elapsed.first. */
+int mm_gemm_launch(int device, const mm_config_t *cfg, const void *a_dev, const void *b_dev,
+                   void *c_dev, unsigned size_n, unsigned size_k, unsigned size_m,
+                   double *elapsed_seconds);
+
+/* Asynchronous launch on a caller-provided hipStream_t (passed as void*; NULL = the default
+ * stream) of the CURRENT device.  No synchronisation, no timing: for callers that own streams,
+ * events and graphs (bench.py, multi-stream pipelines). */
+int mm_gemm_enqueue(void *hip_stream, const mm_config_t *cfg, const void *a_dev,
+                    const void *b_dev, void *c_dev, unsigned size_n, unsigned size_k,
+                    unsigned size_m);
+
+/* One node, `device_count` GPUs, rows of C split into contiguous slabs (device g gets rows
+ * [g*ceil(N/G) ..)), B replicated, no collective.  Host pointers in, host pointer out; copies
+ * are outside the timed region exactly as in RunHardware.cpp:140-190.  *elapsed_seconds = from
+ * a common start to the last device's completion.  New functionality (the reference is
+ * single-device). */
+int mm_gemm_multi_device(int device_count, const mm_config_t *cfg, const void *a_host,
+                         const void *b_host, void *c_host, unsigned size_n, unsigned size_k,
+                         unsigned size_m, double *elapsed_seconds);
+
+/* extern "C" void MatrixMultiplicationKernel(MemoryPackK_t const a[], MemoryPackM_t const b[],
+ * MemoryPackM_t c[], unsigned size_n, unsigned size_k, unsigned size_m)
+ * (include/MatrixMultiplication.h:155-171, kernel/Top.cpp:6-18; called directly by
+ * test/TestSimulation.cpp:66-67).  Host pointers; DataPack arrays are layout-compatible with
+ * plain row-major Data_t arrays (include/Utility.h:44-63).  Uses device 0 and the
+ * configuration set by mm_set_default_config (initially float, Multiply, Add == the
+ * reference's CMake defaults).  Errors are reported on stderr and abort(), because the
+ * reference's symbol returns void. */
+void MatrixMultiplicationKernel(const void *a, const void *b, void *c, unsigned size_n,
+                                unsigned size_k, unsigned size_m);
+int mm_set_default_config(const mm_config_t *cfg);
+
+/* ---- introspection ------------------------------------------------------------------------ */
+size_t mm_dtype_size(mm_dtype_t dtype);
+/* 1 if (dtype, map, reduce) is compiled in, else 0. */
+int mm_config_supported(const mm_config_t *cfg);
+/* Name of the kernel family that mm_gemm_launch would run for this problem (static string),
+ * e.g. "mfma_f32_128x256x32", "valu_tile", "ordered". */
+const char *mm_kernel_name(const mm_config_t *cfg, unsigned size_n, unsigned size_k, unsigned size_m);
+/* Message of the last failing call on this thread (static or thread-local storage). */
+const char *mm_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MM_GEMM_H */

@@ -1,0 +1,72 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads, exports every symbol that
+include/mm_gemm.h declares, the enum values in the header / Python binding / oracle agree, and
+compute calls fail loudly (no CPU fallback) when no GPU is present."""
+import ctypes
+import os
+import re
+
+import pytest
+
+import _oracle
+import gemm_hls_amd as g
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = open(os.path.join(ROOT, "include", "mm_gemm.h")).read()
+
+
+def _has_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+def test_library_exports_every_declared_symbol():
+    L = g.lib()
+    declared = set(re.findall(r"^\s*(?:int|void|size_t|const char \*)\s*\*?\s*(mm_\w+|MatrixMultiplicationKernel)\s*\(",
+                              HEADER, flags=re.M))
+    assert declared == set(g.EXPORTS), declared ^ set(g.EXPORTS)
+    for sym in declared:
+        assert getattr(L, sym) is not None
+
+
+def test_enum_values_agree_header_binding_oracle():
+    def enum_vals(prefix):
+        return {k: int(v) for k, v in re.findall(rf"({prefix}\w+)\s*=\s*(\d+)", HEADER)}
+    d = enum_vals("MM_DTYPE_")
+    want = {"float": "F32", "double": "F64", "half": "F16", "int8_t": "I8", "uint8_t": "U8", "int16_t": "I16",
+            "uint16_t": "U16", "int": "I32", "unsigned": "U32", "long": "I64", "unsigned long": "U64"}
+    for name, tag in want.items():
+        assert d["MM_DTYPE_" + tag] == g.DTYPES[name] == _oracle.DTYPES[name]
+    o = enum_vals("MM_OP_")
+    for name in ("Add", "Multiply", "And", "Min", "Max"):
+        assert o["MM_OP_" + name.upper()] == g.OPS[name] == _oracle.OPS[name]
+    for name, code in g.DTYPES.items():
+        assert g.lib().mm_dtype_size(code) == _oracle.lib().mm_oracle_dtype_size(code)
+
+
+def test_kernel_name_dispatch_table():
+    assert g.kernel_name(g.make_config("float"), 16384, 16384, 16384).startswith("mfma_f32")
+    assert g.kernel_name(g.make_config("float", path=g.PATH_ORDERED), 64, 64, 64) == "ordered"
+    assert not g.kernel_name(g.make_config("float", "Add", "Min"), 64, 64, 64).startswith("mfma")
+    assert not g.kernel_name(g.make_config("float"), 64, 62, 64).startswith("mfma")  # K % 8 != 0
+
+
+@pytest.mark.skipif(_has_gpu(), reason="only meaningful without a GPU")
+def test_compute_fails_loudly_without_gpu():
+    import numpy as np
+    with pytest.raises(g.MMError, match="no CPU fallback|gfx950"):
+        g.device_count()
+    a = np.ones((4, 16), np.float32)
+    with pytest.raises(g.MMError):
+        g.matmul_capi(a, np.ones((16, 16), np.float32))
+    with pytest.raises(g.MMError):
+        g.matmul_host(a, np.ones((16, 16), np.float32))
+
+
+def test_bad_arguments_are_rejected_before_touching_a_device():
+    cfg = g.Config(99, 0, 0, 0, 0)
+    assert g.lib().mm_config_supported(ctypes.byref(cfg)) == 0
+    assert g.lib().mm_set_default_config(ctypes.byref(cfg)) != 0
+    assert b"invalid" in g.lib().mm_last_error()

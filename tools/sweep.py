@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Times kernel variants through the C ABI (mm_gemm_launch: HIP-event kernel time) on
+device-filled operands (uniform [1,10), the reference's input distribution).
+
+  python tools/sweep.py f32 [--sizes 4096,8192,16384] [--variants 0,1,2] [--reps 5]
+"""
+import argparse
+import ctypes
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import gemm_hls_amd as g  # noqa: E402
+
+PEAK = {"float": 157.3, "double": 78.6, "half": 2500.0}
+
+
+def time_config(dtype, mp, rd, n, k, m, reps, path=g.PATH_AUTO):
+    L = g.lib()
+    es = L.mm_dtype_size(g.DTYPES[dtype])
+    cfg = g.make_config(dtype, mp, rd, path)
+    ptrs = [ctypes.c_void_p() for _ in range(3)]
+    for p, cnt in zip(ptrs, (n * k, k * m, n * m)):
+        g._check(L.mm_alloc(0, cnt * es, ctypes.byref(p)))
+    g._check(L.mm_fill_device(0, g.DTYPES[dtype], ptrs[0], n * k, 1))
+    g._check(L.mm_fill_device(0, g.DTYPES[dtype], ptrs[1], k * m, 2))
+    t = ctypes.c_double(0)
+    times = []
+    for i in range(reps + 1):
+        g._check(L.mm_gemm_launch(0, ctypes.byref(cfg), ptrs[0], ptrs[1], ptrs[2], n, k, m, ctypes.byref(t)))
+        if i:
+            times.append(t.value)
+    for p in ptrs:
+        L.mm_free(0, p)
+    times.sort()
+    return times[len(times) // 2], times[0]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("what", choices=["f32", "f64", "f16", "minplus", "all"])
+    ap.add_argument("--sizes", default="4096,8192,16384")
+    ap.add_argument("--variants", default="")
+    ap.add_argument("--reps", type=int, default=5)
+    args = ap.parse_args()
+    sizes = [int(s) for s in args.sizes.split(",")]
+    if args.what == "f32":
+        variants = [int(v) for v in args.variants.split(",")] if args.variants else list(range(8))
+        for v in variants:
+            os.environ["MM_F32_VARIANT"] = str(v)
+            for s in sizes:
+                name = g.kernel_name(g.make_config("float"), s, s, s)
+                med, best = time_config("float", "Multiply", "Add", s, s, s, args.reps)
+                tf = 2.0 * s ** 3 / med / 1e12
+                print(f"f32 v{v} {name:36s} {s:6d}^3  med {med*1e3:9.3f} ms  {tf:7.2f} TF  "
+                      f"({100*tf/PEAK['float']:5.1f}% of 157.3)  best {2.0*s**3/best/1e12:7.2f} TF", flush=True)
+    else:
+        table = {"f64": ("double", "Multiply", "Add"), "f16": ("half", "Multiply", "Add"),
+                 "minplus": ("float", "Add", "Min")}
+        for key in ([args.what] if args.what != "all" else list(table)):
+            dtype, mp, rd = table[key]
+            for s in sizes:
+                name = g.kernel_name(g.make_config(dtype, mp, rd), s, s, s)
+                med, best = time_config(dtype, mp, rd, s, s, s, args.reps)
+                tf = 2.0 * s ** 3 / med / 1e12
+                print(f"{key} {name:30s} {s:6d}^3  med {med*1e3:9.3f} ms  {tf:8.2f} TOp/s  best {2.0*s**3/best/1e12:8.2f}",
+                      flush=True)
+
+
+if __name__ == "__main__":
+    main()
