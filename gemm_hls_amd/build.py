@@ -19,7 +19,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
-OBJ = os.path.join(HERE, "build")
+OBJ = os.path.join(HERE, "_obj")
 BIN = os.path.join(ROOT, "bin")
 LIB = os.path.join(HERE, "libmm_gemm_amd.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -81,7 +81,7 @@ def build(verbose=True):
     host_jobs = []
     host_hdrs = [os.path.join(host_dir, f) for f in os.listdir(host_dir) if f.endswith(".h")] + [
         os.path.join(ROOT, "include", "mm_gemm.h")]
-    rpath = "-Wl,-rpath," + HERE
+    rpath = "-Wl,-rpath,$ORIGIN/../gemm_hls_amd"
     for (dt, mp, rd) in HOST_CONFIGS:
         names = [f"RunHardware_{dt}_{mp}_{rd}.exe"] + (["RunHardware.exe"] if (dt, mp, rd) == HOST_CONFIGS[0] else [])
         src = os.path.join(host_dir, "RunHardware.cpp")

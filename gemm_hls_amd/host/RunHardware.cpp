@@ -1,0 +1,184 @@
+// RunHardware -- host runner with the command line, checks, messages, GOp/s report and exit codes
+// of the reference's host/RunHardware.cpp, driving the MI355X library through its C ABI
+// (include/mm_gemm.h) instead of hlslib's OpenCL wrapper.
+//
+//   RunHardware.exe N K M [<mode [hw/hw_emu]>] [<verify [on/off]>]      (MM_DYNAMIC_SIZES)
+//   RunHardware.exe [<mode [hw/hw_emu]>] [<verify [on/off]>]            (static sizes)
+//
+//   hw      the fast kernel family for this build's (MM_DATA_TYPE, MM_MAP_OP, MM_REDUCE_OP)
+//   hw_emu  the k-ordered kernel that is bit-identical to the reference's Naive (MM_PATH_ORDERED);
+//           like the reference's hw_emu it executes the same contract more slowly, on the device
+//   on/off  verify against ReferenceImplementation (BLAS / Naive) or time only.  With `off` the
+//           reference leaves device memory uninitialised; here it is filled on the device with
+//           the same value distribution so that clocks behave like a real run.
+// Environment: MM_GPUS=<g> splits the rows of C over g devices (no collective; default 1).
+#include <chrono>
+#include <cstdlib>
+#include <iostream>
+#include <random>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "HostReference.h"
+
+namespace {
+
+void PrintUsage() {
+#ifndef MM_DYNAMIC_SIZES
+  std::cerr << "Usage: ./RunHardware.exe <mode [hw/hw_emu]> [<verify [on/off]>]\n" << std::flush;
+#else
+  std::cerr << "Usage: ./RunHardware.exe N K M [<mode [hw/hw_emu]>] [<verify [on/off]>]\n" << std::flush;
+#endif
+}
+
+void Check(int status, const char *what) {
+  if (status != MM_OK) throw std::runtime_error(std::string(what) + ": " + mm_last_error());
+}
+
+// RAII device buffer (the role of hlslib::ocl::Buffer, host/RunHardware.cpp:122-138)
+struct DeviceBuffer {
+  int device;
+  void *ptr = nullptr;
+  size_t bytes;
+  DeviceBuffer(int dev, size_t nbytes) : device(dev), bytes(nbytes) { Check(mm_alloc(dev, nbytes, &ptr), "mm_alloc"); }
+  ~DeviceBuffer() { if (ptr) mm_free(device, ptr); }
+  DeviceBuffer(const DeviceBuffer &) = delete;
+  DeviceBuffer &operator=(const DeviceBuffer &) = delete;
+};
+
+}  // namespace
+
+int main(int argc, char **argv) {
+  bool emulation = false;
+  bool verify = true;
+#ifdef MM_DYNAMIC_SIZES
+  if (argc > 6 || argc < 4) {
+    PrintUsage();
+    return 1;
+  }
+  unsigned size_n, size_k, size_m;
+  try {
+    size_n = std::stoul(argv[1]);
+    size_k = std::stoul(argv[2]);
+    size_m = std::stoul(argv[3]);
+  } catch (std::exception const &) {
+    PrintUsage();
+    return 1;
+  }
+  int next_arg = 4;
+  if (size_k % kMemoryWidthK != 0) {
+    std::cerr << "K (" << size_k << ") must be divisable by the memory width in K (" << kMemoryWidthK << ")." << std::endl;
+    return 1;
+  }
+  if (size_m % kMemoryWidthM != 0) {
+    std::cerr << "M (" << size_m << ") must be divisable by the memory width in M (" << kMemoryWidthM << ")." << std::endl;
+    return 1;
+  }
+#else
+  if (argc > 3) {
+    PrintUsage();
+    return 1;
+  }
+  constexpr unsigned size_n = kSizeN, size_k = kSizeK, size_m = kSizeM;
+  int next_arg = 1;
+#endif
+  if (next_arg < argc) {
+    const std::string mode(argv[next_arg++]);
+    if (mode == "hw_emu") {
+      emulation = true;
+    } else if (mode != "hw") {
+      PrintUsage();
+      return 1;
+    }
+  }
+  if (next_arg < argc) {
+    const std::string v(argv[next_arg++]);
+    if (v == "off") {
+      verify = false;
+    } else if (v != "on") {
+      PrintUsage();
+      return 1;
+    }
+  }
+  const int gpus = std::getenv("MM_GPUS") ? std::max(1, std::atoi(std::getenv("MM_GPUS"))) : 1;
+
+  const mm_config_t cfg = {mmhost::DTypeOf<Data_t>::value, OperatorMap::code, OperatorReduce::code,
+                           emulation ? MM_PATH_ORDERED : MM_PATH_AUTO, MM_A_ROW_MAJOR};
+  const size_t count_a = (size_t)size_n * size_k, count_b = (size_t)size_k * size_m, count_c = (size_t)size_n * size_m;
+
+  std::vector<Data_t> a, b, cRef, cTest;
+  std::cout << "Initializing host memory..." << std::flush;
+  if (verify || gpus > 1) {
+    // The reference's generator: ONE engine seeded with kSeed, real or integer uniform on [1, 10],
+    // all of A drawn first, then all of B (host/RunHardware.cpp:31-35,99-105).
+    std::default_random_engine rng(kSeed);
+    typename std::conditional<std::is_integral<Data_t>::value, std::uniform_int_distribution<unsigned long>,
+                              std::uniform_real_distribution<double>>::type dist(1, 10);
+    a.resize(count_a);
+    b.resize(count_b);
+    for (auto &x : a) x = Data_t(dist(rng));
+    for (auto &x : b) x = Data_t(dist(rng));
+    cTest.assign(count_c, Data_t(0));
+    if (verify) cRef.assign(count_c, Data_t(0));
+  }
+  std::cout << " Done.\n";
+
+  try {
+    std::cout << "Initializing HIP context...\n" << std::flush;
+    int device_count = 0;
+    Check(mm_init(&device_count), "mm_init");
+    if (gpus > device_count) throw std::runtime_error("MM_GPUS exceeds the number of visible devices");
+
+    double elapsed = 0.0;
+    if (gpus > 1) {
+      std::cout << "Initializing device memory on " << gpus << " devices, copying row slabs of A and C and replicas of B...\n"
+                << std::flush;
+      std::cout << "Executing kernel...\n" << std::flush;
+      Check(mm_gemm_multi_device(gpus, &cfg, a.data(), b.data(), cTest.data(), size_n, size_k, size_m, &elapsed),
+            "mm_gemm_multi_device");
+    } else {
+      std::cout << "Initializing device memory...\n" << std::flush;
+      DeviceBuffer aDevice(0, count_a * sizeof(Data_t)), bDevice(0, count_b * sizeof(Data_t)),
+          cDevice(0, count_c * sizeof(Data_t));
+      if (verify) {
+        std::cout << "Copying memory to device...\n" << std::flush;
+        Check(mm_copy_to_device(0, aDevice.ptr, a.data(), aDevice.bytes), "copy A");
+        Check(mm_copy_to_device(0, bDevice.ptr, b.data(), bDevice.bytes), "copy B");
+        Check(mm_copy_to_device(0, cDevice.ptr, cTest.data(), cDevice.bytes), "copy C");
+      } else {
+        Check(mm_fill_device(0, cfg.dtype, aDevice.ptr, count_a, 1), "fill A");
+        Check(mm_fill_device(0, cfg.dtype, bDevice.ptr, count_b, 2), "fill B");
+      }
+      std::cout << "Creating kernel...\n" << std::flush;
+      std::cout << "Executing kernel (" << mm_kernel_name(&cfg, size_n, size_k, size_m) << ")...\n" << std::flush;
+      if (!verify) {  // timing run: one untimed launch first so that code upload is not in the number
+        Check(mm_gemm_launch(0, &cfg, aDevice.ptr, bDevice.ptr, cDevice.ptr, size_n, size_k, size_m, nullptr), "warm-up");
+      }
+      Check(mm_gemm_launch(0, &cfg, aDevice.ptr, bDevice.ptr, cDevice.ptr, size_n, size_k, size_m, &elapsed),
+            "mm_gemm_launch");
+      if (verify) {
+        std::cout << "Copying back result...\n" << std::flush;
+        Check(mm_copy_to_host(0, cTest.data(), cDevice.ptr, cDevice.bytes), "copy back");
+      }
+    }
+    const auto perf = 1e-9 * (2 * static_cast<float>(size_n) * size_k * size_m) / elapsed;
+    std::cout << "Kernel executed in " << elapsed << " seconds, corresponding to a performance of " << perf << " GOp/s.\n";
+  } catch (std::runtime_error const &err) {
+    std::cerr << "Execution failed with error: \"" << err.what() << "\"." << std::endl;
+    return 1;
+  }
+
+  if (verify) {
+    std::cout << "Running reference implementation...\n" << std::flush;
+    const auto t0 = std::chrono::steady_clock::now();
+    mmhost::ReferenceImplementation<Data_t, OperatorMap, OperatorReduce>(a.data(), b.data(), cRef.data(), size_n, size_k,
+                                                                         size_m);
+    const double tref = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    std::cout << "Reference implementation took " << tref << " seconds on " << mmhost::HostThreads() << " host threads.\n";
+    std::cout << "Verifying result...\n" << std::flush;
+    if (!mmhost::Verify(cTest.data(), cRef.data(), size_n, size_m)) return 1;
+    std::cout << "Successfully verified." << std::endl;
+  }
+  return 0;
+}

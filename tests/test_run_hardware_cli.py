@@ -1,0 +1,102 @@
+"""The C++ host runner keeps the reference's command line (host/RunHardware.cpp:18-91): argument
+count, size checks with the reference's messages, mode/verify keywords, exit codes."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "bin", "RunHardware.exe")
+USAGE = "Usage: ./RunHardware.exe N K M [<mode [hw/hw_emu]>] [<verify [on/off]>]"
+
+
+def run(exe, *args, env=None):
+    e = dict(os.environ)
+    e.update(env or {})
+    return subprocess.run([exe, *map(str, args)], capture_output=True, text=True, env=e, timeout=1200)
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _built():
+    if not os.path.exists(EXE):
+        import sys
+        sys.path.insert(0, ROOT)
+        from gemm_hls_amd import build
+        build.build(verbose=False)
+
+
+@pytest.mark.parametrize("args", [(), (64,), (64, 64), (64, 64, 64, "hw", "on", "extra"), (64, 64, 64, "fpga"),
+                                  (64, 64, 64, "hw", "maybe")])
+def test_usage_errors(args):
+    r = run(EXE, *args)
+    assert r.returncode == 1 and USAGE in r.stderr
+
+
+def test_divisibility_messages():
+    r = run(EXE, 64, 17, 64)
+    assert r.returncode == 1
+    assert "K (17) must be divisable by the memory width in K (16)." in r.stderr
+    r = run(EXE, 64, 16, 24)
+    assert r.returncode == 1
+    assert "M (24) must be divisable by the memory width in M (16)." in r.stderr
+    # double: 64-byte bus = 8 elements
+    r = run(os.path.join(ROOT, "bin", "RunHardware_double_Multiply_Add.exe"), 64, 12, 64)
+    assert "memory width in K (8)" in r.stderr
+
+
+def _has_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+@pytest.mark.skipif(_has_gpu(), reason="only meaningful without a GPU")
+def test_no_device_is_an_execution_failure_not_a_fallback():
+    r = run(EXE, 64, 16, 64)
+    assert r.returncode == 1
+    assert r.stderr.startswith('Execution failed with error: "') and "no CPU fallback" in r.stderr
+    assert "Successfully verified." not in r.stdout
+
+
+PERF_LINE = re.compile(r"Kernel executed in ([\d\.e\-+]+) seconds, corresponding to a performance of ([\d\.e\-+]+) GOp/s\.")
+# the regex the reference's benchmark driver applies to this output (scripts/build_manager.py:601-602)
+BUILD_MANAGER_RE = re.compile(r"([\d\.]+) seconds[^\d]+([\d\.]+) GOp/s")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("exe,shape", [
+    ("RunHardware.exe", (513, 528, 528)),                    # the reference's CTest shape
+    ("RunHardware_double_Multiply_Add.exe", (257, 264, 264)),
+    ("RunHardware_half_Multiply_Add.exe", (129, 160, 288)),
+    ("RunHardware_float_Add_Min.exe", (257, 272, 272)),
+    ("RunHardware_int_Multiply_Add.exe", (257, 272, 272)),
+    ("RunHardware_uint8_t_Multiply_Add.exe", (129, 192, 192)),
+])
+@pytest.mark.parametrize("mode", ["hw", "hw_emu"])
+def test_run_hardware_verifies_on_gpu(exe, shape, mode):
+    if "half" in exe and mode == "hw_emu":
+        pytest.skip("hw_emu accumulates in half like the reference; the host check uses the wide contract")
+    r = run(os.path.join(ROOT, "bin", exe), *shape, mode, "on")
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert PERF_LINE.search(r.stdout) and "Successfully verified." in r.stdout
+
+
+@pytest.mark.gpu
+def test_run_hardware_timing_only_and_report_format():
+    r = run(EXE, 4096, 4096, 4096, "hw", "off")
+    assert r.returncode == 0, r.stdout + r.stderr
+    m = PERF_LINE.search(r.stdout)
+    assert m and "Verifying" not in r.stdout
+    secs, gops = float(m.group(1)), float(m.group(2))
+    assert abs(gops - 1e-9 * 2 * 4096.0 ** 3 / secs) / gops < 1e-3
+    assert gops > 50e3  # an MI355X does far better than 50 TFLOP/s on this
+    assert BUILD_MANAGER_RE.search(r.stdout)
+
+
+@pytest.mark.gpu
+def test_run_hardware_multi_gpu_env_single_device():
+    r = run(EXE, 300, 64, 272, "hw", "on", env={"MM_GPUS": "1"})
+    assert r.returncode == 0 and "Successfully verified." in r.stdout
