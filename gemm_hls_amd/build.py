@@ -60,7 +60,7 @@ def run(cmd):
 def build(verbose=True):
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(BIN, exist_ok=True)
-    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))]
     headers.append(os.path.join(ROOT, "include", "mm_gemm.h"))
     sources = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
     jobs = []

@@ -90,6 +90,20 @@ int launch_fill(hipStream_t s, mm_dtype_t dtype, void *ptr, size_t elements, uns
 
 constexpr int kErrNotSupported = 801;  // hipErrorNotSupported
 
+// Kernels that need more than 64 KiB of dynamic LDS must opt in once per (function, device).
+// `mask` is a per-kernel static bitmask of devices already configured.
+inline int ensure_dynamic_lds(const void *func, int bytes, unsigned long long &mask) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return (int)e;
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (__atomic_load_n(&mask, __ATOMIC_ACQUIRE) & bit) return 0;
+  e = hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) return (int)e;
+  __atomic_fetch_or(&mask, bit, __ATOMIC_RELEASE);
+  return 0;
+}
+
 // XCD-aware remap of a 1-D workgroup id: the dispatcher places workgroup b on XCD b % 8
 // (observed, used for speed only); give every XCD one contiguous chunk of the tile order so that
 // tiles sharing A row-panels / B column-panels meet in the same private L2.  Bijective for any

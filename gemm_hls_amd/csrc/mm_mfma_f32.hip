@@ -271,13 +271,8 @@ __global__ __launch_bounds__(G::THREADS) void mfma_f32_kernel(const float *__res
 template <typename G>
 int launch_geo(hipStream_t s, const Problem &p) {
   const unsigned tiles_n = (p.n + G::BM - 1) / G::BM, tiles_m = (p.m + G::BN - 1) / G::BN;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void *)mfma_f32_kernel<G>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  static unsigned long long configured = 0;
+  if (int e = ensure_dynamic_lds((const void *)mfma_f32_kernel<G>, G::LDS_BYTES, configured)) return e;
   hipLaunchKernelGGL((mfma_f32_kernel<G>), dim3(tiles_n * tiles_m), dim3(G::THREADS), G::LDS_BYTES, s,
                      (const float *)p.a, (const float *)p.b, (float *)p.c, p.n, p.k, p.m, tiles_n, tiles_m);
   return (int)hipGetLastError();

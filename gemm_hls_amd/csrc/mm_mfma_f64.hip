@@ -1,0 +1,205 @@
+// fp64 (Multiply, Add) fast path for gfx950: C[N x M] = A[N x K] . B[K x M], row-major, on
+// v_mfma_f64_16x16x4_f64.  Same organisation as the fp32 kernel (mm_mfma_f32.hip: resident output
+// tile in accumulation registers for the whole K loop -- kernel/Compute.cpp:58-60 -- A row-panel /
+// B column-panel k-slabs DMA'd to an LDS ring -- the role of kernel/Memory.cpp's ReadA/ReadB/FeedB),
+// with the fragment shapes of the f64 instruction:
+//   operands: lane l supplies A[i = l&15][k = l>>4] and B[k = l>>4][j = l&15] (one f64 each);
+//   result:   4 f64 per lane, column l&15, rows (l>>4) + 4*r   (NOT the f32 row map).
+// Workgroup = WM x WN wavefronts, each owning 64 x 64 of C as 4 x 4 accumulators (128 registers).
+// K slab = 16 doubles: an A row is 128 B = 8 chunks of 16 B, XOR-swizzled with (row>>1)&7 on the
+// DMA source address so that every ds_read_b128 service group touches 16 distinct 16-B slots.
+// Fragment reads (all ds_read_b128 = 2 doubles):
+//   A: lane reads A[row = l&15][2 consecutive k at k-offset 2*(l>>4)] -> feeds 2 MFMAs of an
+//      8-deep k-group, MFMA p using k = {2g+p : g = 0..3};
+//   B: lane reads B[k = 2*(l>>4)+p][2 consecutive columns 2*(l&15)..+1] -> feeds 2 column
+//      accumulators (accumulator t holds columns 2*j+t), so the epilogue stores 16 B per lane.
+// Accumulation: one f64 fma chain per element (k order 0,2,4,6,1,3,5,7 inside each group).
+// Edges: N arbitrary, M % 2 == 0, K % 8 == 0 (the reference's own contract for double is
+// K % 8 == 0 and M % 8 == 0, host/RunHardware.cpp:50-61); other shapes -> predicated kernels.
+#include "mm_common.h"
+
+namespace mm {
+namespace {
+
+using f64x2 = __attribute__((ext_vector_type(2))) double;
+using f64x4 = __attribute__((ext_vector_type(4))) double;
+typedef const __attribute__((address_space(1))) void *gptr_t;
+typedef __attribute__((address_space(3))) void *lptr_t;
+
+template <int WM_, int WN_, int NS_>
+struct GeoD {
+  static constexpr int WM = WM_, WN = WN_, NS = NS_;
+  static constexpr int TM = 4, TP = 2;               // 4 row tiles x (2 pairs of column tiles) of 16
+  static constexpr int NW = WM * WN, THREADS = NW * 64;
+  static constexpr int BM = WM * 64, BN = WN * 64, BK = 16;
+  static constexpr int CPR = 8;                      // 16-B chunks per A row (16 doubles)
+  static constexpr int A_BYTES = BM * BK * 8, B_BYTES = BK * BN * 8;
+  static constexpr int STAGE_BYTES = A_BYTES + B_BYTES, LDS_BYTES = NS * STAGE_BYTES;
+  static constexpr int NA = A_BYTES / 1024, NB = B_BYTES / 1024;
+  static constexpr int LA = NA / NW, LB = NB / NW;
+  static constexpr int KG = BK / 8;
+  static constexpr int BCH = BN / 2;                 // 16-B chunks per B k-row
+  static_assert(NA % NW == 0 && NB % NW == 0, "DMA split");
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+};
+
+template <typename G>
+__global__ __launch_bounds__(G::THREADS) void mfma_f64_kernel(const double *__restrict__ A,
+                                                              const double *__restrict__ B,
+                                                              double *__restrict__ C, unsigned N, unsigned K,
+                                                              unsigned M, unsigned tiles_n, unsigned tiles_m) {
+  constexpr int TM = G::TM, TP = G::TP, BK = G::BK, NS = G::NS, CPR = G::CPR;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const unsigned lane = threadIdx.x & 63u;
+  const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const unsigned wm = wave / G::WN, wn = wave % G::WN;
+  const unsigned lo = lane & 15u, g4 = lane >> 4;
+
+  const unsigned nwg = tiles_n * tiles_m;
+  const unsigned lin = xcd_remap(blockIdx.x, nwg);
+  constexpr unsigned kBand = 8;
+  const unsigned band = lin / (kBand * tiles_m), within = lin % (kBand * tiles_m);
+  const unsigned rows_in_band = min(kBand, tiles_n - band * kBand);
+  const unsigned row0 = (band * kBand + within % rows_in_band) * G::BM, col0 = (within / rows_in_band) * G::BN;
+
+  size_t a_row_off[G::LA];
+  unsigned a_kchunk[G::LA];
+#pragma unroll
+  for (int i = 0; i < G::LA; ++i) {
+    const unsigned slot = (wave + G::NW * i) * 64 + lane;
+    const unsigned row = slot / CPR, pc = slot % CPR;
+    a_kchunk[i] = pc ^ ((row >> 1) & (CPR - 1));
+    a_row_off[i] = (size_t)min(row0 + row, N - 1) * K;
+  }
+  unsigned b_krow[G::LB], b_col[G::LB];
+#pragma unroll
+  for (int i = 0; i < G::LB; ++i) {
+    const unsigned slot = (wave + G::NW * i) * 64 + lane;
+    b_krow[i] = slot / G::BCH;
+    b_col[i] = min(col0 + (slot % G::BCH) * 2, M - 2);
+  }
+  auto stage = [&](unsigned buf, unsigned k0) {
+    char *base = smem + buf * G::STAGE_BYTES;
+#pragma unroll
+    for (int i = 0; i < G::LA; ++i) {
+      const unsigned kk = min(k0 + a_kchunk[i] * 2, K - 2);
+      __builtin_amdgcn_global_load_lds((gptr_t)(A + a_row_off[i] + kk), (lptr_t)(base + (wave + G::NW * i) * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < G::LB; ++i) {
+      const unsigned kr = min(k0 + b_krow[i], K - 1);
+      __builtin_amdgcn_global_load_lds((gptr_t)(B + (size_t)kr * M + b_col[i]),
+                                       (lptr_t)(base + G::A_BYTES + (wave + G::NW * i) * 1024), 16, 0, 0);
+    }
+  };
+
+  // A: row = wm*64 + mi*16 + lo; chunk = (4*kg + g4) ^ swz(lo)
+  const unsigned a_swz = (lo >> 1) & (CPR - 1);
+  const unsigned a_frag_base = (wm * 64 + lo) * (BK * 8);
+  // B: k = kg*8 + 2*g4 + p; col = wn*64 + pair*32 + 2*lo
+  const unsigned b_frag_base = G::A_BYTES + (2 * g4) * (G::BN * 8) + (wn * 64 + 2 * lo) * 8;
+
+  f64x4 acc[TM][TP][2];
+#pragma unroll
+  for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+    for (int pr = 0; pr < TP; ++pr) {
+      acc[mi][pr][0] = (f64x4)0.0;
+      acc[mi][pr][1] = (f64x4)0.0;
+    }
+
+  auto load_frags = [&](unsigned buf, int kg, f64x2 (&af)[TM], f64x2 (&bf)[2][TP]) {
+    const char *base = smem + buf * G::STAGE_BYTES;
+    const unsigned achunk = (((unsigned)(4 * kg) + g4) ^ a_swz) * 16;
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) af[mi] = *(const f64x2 *)(base + a_frag_base + mi * 16 * (BK * 8) + achunk);
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int pr = 0; pr < TP; ++pr)
+        bf[p][pr] = *(const f64x2 *)(base + b_frag_base + (kg * 8 + p) * (G::BN * 8) + pr * 32 * 8);
+  };
+  auto mfma_group = [&](const f64x2 (&af)[TM], const f64x2 (&bf)[2][TP]) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+        for (int pr = 0; pr < TP; ++pr) {
+          acc[mi][pr][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[mi][p], bf[p][pr][0], acc[mi][pr][0], 0, 0, 0);
+          acc[mi][pr][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[mi][p], bf[p][pr][1], acc[mi][pr][1], 0, 0, 0);
+        }
+  };
+
+  const unsigned num_tiles = (K + BK - 1) / BK;
+  constexpr int L = G::LA + G::LB;
+#pragma unroll
+  for (int s = 0; s < NS; ++s) stage(s, s * BK);
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 1) * L) : "memory");
+  __builtin_amdgcn_s_barrier();
+
+  f64x2 af0[TM], bf0[2][TP], af1[TM], bf1[2][TP];
+  load_frags(0, 0, af0, bf0);
+
+  // one full slab with a successor; KG == 2: group 0 from set 0, group 1 from set 1 (see f32 kernel)
+  const unsigned steady = num_tiles - 1;
+  for (unsigned t = 0; t < steady; ++t) {
+    const unsigned buf = t % NS;
+    load_frags(buf, 1, af1, bf1);
+    mfma_group(af0, bf0);
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NS - 2) * L) : "memory");
+    __builtin_amdgcn_s_barrier();
+    stage(buf, (t + NS) * BK);
+    load_frags((t + 1) % NS, 0, af0, bf0);
+    mfma_group(af1, bf1);
+  }
+  {
+    const unsigned t = num_tiles - 1;
+    const int groups = (int)((K - t * BK) / 8);
+    for (int kg = 0; kg < groups; ++kg) {
+      load_frags(t % NS, kg, af0, bf0);
+      mfma_group(af0, bf0);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // trailing ring refills (clamped, unread)
+
+  // epilogue: lane owns 2 consecutive columns of rows g4 + 4*r
+#pragma unroll
+  for (int pr = 0; pr < TP; ++pr) {
+    const unsigned ccol = col0 + wn * 64 + pr * 32 + 2 * lo;
+    if (ccol >= M) continue;
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const unsigned row = row0 + wm * 64 + mi * 16 + g4 + 4 * r;
+        if (row < N) {
+          f64x2 v;
+          v[0] = acc[mi][pr][0][r];
+          v[1] = acc[mi][pr][1][r];
+          *(f64x2 *)(C + (size_t)row * M + ccol) = v;
+        }
+      }
+  }
+}
+
+using D0 = GeoD<4, 2, 2>;  // 256 x 128 tile, 8 wavefronts (2 per SIMD), 96 KiB LDS
+
+}  // namespace
+
+bool mfma_f64_serves(const Problem &p) {
+  return !p.a_transposed && p.n >= 1 && p.m >= 2 && p.k >= 8 && p.m % 2 == 0 && p.k % 8 == 0;
+}
+
+int launch_mfma_f64(hipStream_t s, const Problem &p) {
+  if (!mfma_f64_serves(p)) return kErrNotSupported;
+  using G = D0;
+  const unsigned tiles_n = (p.n + G::BM - 1) / G::BM, tiles_m = (p.m + G::BN - 1) / G::BN;
+  static unsigned long long configured = 0;
+  if (int e = ensure_dynamic_lds((const void *)mfma_f64_kernel<G>, G::LDS_BYTES, configured)) return e;
+  hipLaunchKernelGGL((mfma_f64_kernel<G>), dim3(tiles_n * tiles_m), dim3(G::THREADS), G::LDS_BYTES, s,
+                     (const double *)p.a, (const double *)p.b, (double *)p.c, p.n, p.k, p.m, tiles_n, tiles_m);
+  return (int)hipGetLastError();
+}
+
+}  // namespace mm

@@ -2,9 +2,6 @@
 // with another GPU family (never the CPU).  Entries disappear from here as families land.
 #include "mm_common.h"
 namespace mm {
-bool mfma_f64_serves(const Problem &) { return false; }
 bool mfma_f16_serves(const Problem &) { return false; }
-int launch_mfma_f64(hipStream_t, const Problem &) { return kErrNotSupported; }
 int launch_mfma_f16(hipStream_t, const Problem &) { return kErrNotSupported; }
-int launch_valu_tile(hipStream_t, const mm_config_t &, const Problem &) { return kErrNotSupported; }
 }  // namespace mm
