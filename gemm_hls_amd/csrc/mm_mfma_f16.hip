@@ -1,0 +1,241 @@
+// half (Multiply, Add) fast path for gfx950: C[N x M] = A[N x K] . B[K x M], row-major binary16
+// in and out, on v_mfma_f32_32x32x16_f16.
+//
+// Numerical contract: products of two binary16 values are exact in f32;
+// they are accumulated in f32 by the matrix core and rounded to binary16 ONCE on store.  The
+// reference's HLS kernel accumulates in half (and overflows to inf beyond K ~ 2000 on its own
+// [1,10) inputs); the k-ordered kernel (MM_PATH_ORDERED) reproduces that behaviour exactly.
+//
+// Organisation as in mm_mfma_f32.hip (resident output tile, LDS ring fed by global_load_lds):
+//   workgroup 256 x 256, 8 wavefronts as 4 x 2, each 64 x 128 = 2 x 4 accumulators of 32 x 32;
+//   K slab = 64 halves (an A row is 128 B = 8 chunks of 16 B, swizzled with (row>>1)&7);
+//   A fragment: ds_read_b128 = A[row = l&31][8 consecutive k at 8*(l>>5)] -- exactly the operand;
+//   B fragment: B is K x M row-major, the operand wants 8 consecutive k of ONE column, so the
+//     LDS image stays row-major [k][256 cols] and the operand is gathered by two
+//     ds_read_b64_tr_b16 (hardware 4 x 16 transpose: lane i of a 16-lane group receives column i
+//     of the [4 k][16 col] block whose rows the group's lanes point at;
+//     out[i][j] = in[4j + (i>>2)][i&3], profiles/r01_probe_ds_read_b64_tr_b16.txt).
+//     A B k-row is 512 B, so the 4 rows of a block would share banks; the 16-B chunk index is
+//     XORed with (k&3)<<2 on the DMA source side, which spreads the 4 rows over the 4 quadrants
+//     of the 256-B bank row: each half-wave then reads 256 distinct bytes.
+// Edges: N arbitrary, K % 16 == 0, M % 8 == 0 (reference contract for half: K % 32, M % 32).
+#include "mm_common.h"
+
+namespace mm {
+namespace {
+
+using h8 = __attribute__((ext_vector_type(8))) _Float16;
+using h4 = __attribute__((ext_vector_type(4))) _Float16;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+typedef short s4 __attribute__((vector_size(8)));
+typedef const __attribute__((address_space(1))) void *gptr_t;
+typedef __attribute__((address_space(3))) void *lptr_t;
+
+struct GeoH {
+  static constexpr int WM = 4, WN = 2, NS = 2;
+  static constexpr int TM = 2, TN = 4;
+  static constexpr int NW = WM * WN, THREADS = NW * 64;
+  static constexpr int BM = WM * TM * 32, BN = WN * TN * 32, BK = 64;  // 256 x 256 x 64
+  static constexpr int CPR = 8;                                        // 16-B chunks per A row
+  static constexpr int BROW = BN * 2, BCH = BROW / 16;                 // B k-row bytes / chunks
+  static constexpr int A_BYTES = BM * BK * 2, B_BYTES = BK * BROW;
+  static constexpr int STAGE_BYTES = A_BYTES + B_BYTES, LDS_BYTES = NS * STAGE_BYTES;
+  static constexpr int NA = A_BYTES / 1024, NB = B_BYTES / 1024;
+  static constexpr int LA = NA / NW, LB = NB / NW;
+  static constexpr int KS = BK / 16;                                   // MFMA k-steps per slab
+  static_assert(NA % NW == 0 && NB % NW == 0, "DMA split");
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+};
+
+// LDS-DMA issued from inline asm.  hipcc waits vmcnt(0) before every ds_read_b64_tr_b16 that
+// follows a __builtin_amdgcn_global_load_lds (the transpose-read builtin carries no alias
+// information, so the pending-DMA hazard check is conservative), which would serialise the ring.
+// An asm DMA is invisible to that bookkeeping; its completion is tracked by the kernel's own
+// counted s_waitcnt vmcnt(N) + barrier.  M0 (LDS base of the DMA) is saved and restored inside the
+// same statement because the compiler owns it.
+__device__ __forceinline__ void dma16(const void *gsrc, unsigned lds_byte_addr) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_byte_addr)
+      : "memory");
+}
+
+__device__ __forceinline__ h8 join(s4 lo, s4 hi) {
+  union { s4 s[2]; h8 h; } u;
+  u.s[0] = lo;
+  u.s[1] = hi;
+  return u.h;
+}
+
+__global__ __launch_bounds__(GeoH::THREADS) void mfma_f16_kernel(const _Float16 *__restrict__ A,
+                                                                 const _Float16 *__restrict__ B,
+                                                                 _Float16 *__restrict__ C, unsigned N, unsigned K,
+                                                                 unsigned M, unsigned tiles_n, unsigned tiles_m) {
+  using G = GeoH;
+  constexpr int TM = G::TM, TN = G::TN, BK = G::BK, NS = G::NS, CPR = G::CPR;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const unsigned lane = threadIdx.x & 63u;
+  const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const unsigned wm = wave / G::WN, wn = wave % G::WN;
+  const unsigned lo = lane & 31u, hi = lane >> 5;
+
+  const unsigned nwg = tiles_n * tiles_m;
+  const unsigned lin = xcd_remap(blockIdx.x, nwg);
+  constexpr unsigned kBand = 8;
+  const unsigned band = lin / (kBand * tiles_m), within = lin % (kBand * tiles_m);
+  const unsigned rows_in_band = min(kBand, tiles_n - band * kBand);
+  const unsigned row0 = (band * kBand + within % rows_in_band) * G::BM, col0 = (within / rows_in_band) * G::BN;
+
+  // ---- DMA sources ---------------------------------------------------------------------------
+  size_t a_row_off[G::LA];
+  unsigned a_kchunk[G::LA];
+#pragma unroll
+  for (int i = 0; i < G::LA; ++i) {
+    const unsigned slot = (wave + G::NW * i) * 64 + lane;
+    const unsigned row = slot / CPR, pc = slot % CPR;
+    a_kchunk[i] = pc ^ ((row >> 1) & (CPR - 1));
+    a_row_off[i] = (size_t)min(row0 + row, N - 1) * K;
+  }
+  unsigned b_krow[G::LB], b_col[G::LB];
+#pragma unroll
+  for (int i = 0; i < G::LB; ++i) {
+    const unsigned slot = (wave + G::NW * i) * 64 + lane;
+    const unsigned kr = slot / G::BCH, pc = slot % G::BCH;
+    const unsigned lc = pc ^ ((kr & 3u) << 2);  // k0 is a multiple of 4, so (k0+kr)&3 == kr&3
+    b_krow[i] = kr;
+    b_col[i] = min(col0 + lc * 8, M - 8);
+  }
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
+  auto stage = [&](unsigned buf, unsigned k0) {
+    const unsigned base = lds0 + buf * G::STAGE_BYTES;
+#pragma unroll
+    for (int i = 0; i < G::LA; ++i) {
+      const unsigned kk = min(k0 + a_kchunk[i] * 8, K - 8);
+      dma16(A + a_row_off[i] + kk, base + (wave + G::NW * i) * 1024);
+    }
+#pragma unroll
+    for (int i = 0; i < G::LB; ++i) {
+      const unsigned kr = min(k0 + b_krow[i], K - 1);
+      dma16(B + (size_t)kr * M + b_col[i], base + G::A_BYTES + (wave + G::NW * i) * 1024);
+    }
+  };
+
+  // ---- fragment addresses ----------------------------------------------------------------------
+  // A: row = wm*64 + mi*32 + lo, chunk = (2*ks + hi) ^ swz(lo) = (2*ks) ^ (hi ^ swz)
+  const unsigned a_swz = hi ^ ((lo >> 1) & (CPR - 1));
+  const unsigned a_frag_base = (wm * TM * 32 + lo) * (BK * 2);
+  // B (tr read): x = lane & 15, group column half gq = (lane >> 4) & 1, r = x >> 2 (k row in block)
+  //   k = ks*16 + 8*hi + 4*h + r ; logical chunk = wn*16 + ni*4 + 2*gq + ((x&3)>>1) ; +8 B if x odd
+  //   physical chunk = logical ^ (r << 2)  ->  ni' = ni ^ r
+  const unsigned x = lane & 15u, gq = (lane >> 4) & 1u, r = x >> 2;
+  const unsigned b_lane_base = G::A_BYTES + (8 * hi + r) * G::BROW + (wn * 16 + 2 * gq + ((x & 3u) >> 1)) * 16 + (x & 1u) * 8;
+  unsigned b_ni_off[TN];
+#pragma unroll
+  for (int ni = 0; ni < TN; ++ni) b_ni_off[ni] = b_lane_base + ((unsigned)ni ^ r) * 64;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni) acc[mi][ni] = (f32x16)0.0f;
+
+  auto load_frags = [&](unsigned buf, int ks, h8 (&af)[TM], h8 (&bf)[TN]) {
+    const char *base = smem + buf * G::STAGE_BYTES;
+    const unsigned achunk = ((unsigned)(2 * ks) ^ a_swz) * 16;
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) af[mi] = *(const h8 *)(base + a_frag_base + mi * 32 * (BK * 2) + achunk);
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni) {
+      const char *p = base + b_ni_off[ni] + ks * 16 * G::BROW;
+      const s4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s4 __attribute__((address_space(3))) *)(lptr_t)p);
+      const s4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s4 __attribute__((address_space(3))) *)(lptr_t)(p + 4 * G::BROW));
+      bf[ni] = join(v0, v1);
+    }
+  };
+  auto mfma_step = [&](const h8 (&af)[TM], const h8 (&bf)[TN]) {
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < TN; ++ni)
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+  };
+
+  const unsigned num_tiles = (K + BK - 1) / BK;
+  constexpr int L = G::LA + G::LB;
+#pragma unroll
+  for (int s = 0; s < NS; ++s) stage(s, s * BK);
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 1) * L) : "memory");
+  __builtin_amdgcn_s_barrier();
+
+  h8 af0[TM], bf0[TN], af1[TM], bf1[TN];
+  load_frags(0, 0, af0, bf0);
+
+  const unsigned steady = num_tiles - 1;
+  for (unsigned t = 0; t < steady; ++t) {
+    const unsigned buf = t % NS;
+#pragma unroll
+    for (int ks = 0; ks < G::KS; ++ks) {
+      h8(&afc)[TM] = (ks & 1) ? af1 : af0;
+      h8(&bfc)[TN] = (ks & 1) ? bf1 : bf0;
+      h8(&afn)[TM] = (ks & 1) ? af0 : af1;
+      h8(&bfn)[TN] = (ks & 1) ? bf0 : bf1;
+      if (ks + 1 < G::KS) {
+        load_frags(buf, ks + 1, afn, bfn);
+      } else {
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NS - 2) * L) : "memory");
+        __builtin_amdgcn_s_barrier();
+        stage(buf, (t + NS) * BK);
+        load_frags((t + 1) % NS, 0, afn, bfn);
+      }
+      mfma_step(afc, bfc);
+    }
+  }
+  {
+    const unsigned t = num_tiles - 1;
+    const int steps = (int)((K - t * BK) / 16);
+    for (int ks = 0; ks < steps; ++ks) {
+      load_frags(t % NS, ks, af0, bf0);
+      mfma_step(af0, bf0);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // trailing ring refills (clamped, unread)
+
+  // ---- epilogue: one rounding f32 -> binary16; lane = one column, 32 lanes = 64 contiguous B --
+#pragma unroll
+  for (int ni = 0; ni < TN; ++ni) {
+    const unsigned col = col0 + wn * 128 + ni * 32 + lo;
+    if (col >= M) continue;
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) {
+        const unsigned row = row0 + wm * TM * 32 + mi * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * hi;
+        if (row < N) C[(size_t)row * M + col] = (_Float16)acc[mi][ni][rr];
+      }
+  }
+}
+
+}  // namespace
+
+bool mfma_f16_serves(const Problem &p) {
+  return !p.a_transposed && p.n >= 1 && p.m >= 8 && p.k >= 16 && p.m % 8 == 0 && p.k % 16 == 0;
+}
+
+int launch_mfma_f16(hipStream_t s, const Problem &p) {
+  if (!mfma_f16_serves(p)) return kErrNotSupported;
+  using G = GeoH;
+  const unsigned tiles_n = (p.n + G::BM - 1) / G::BM, tiles_m = (p.m + G::BN - 1) / G::BN;
+  static unsigned long long configured = 0;
+  if (int e = ensure_dynamic_lds((const void *)mfma_f16_kernel, G::LDS_BYTES, configured)) return e;
+  hipLaunchKernelGGL(mfma_f16_kernel, dim3(tiles_n * tiles_m), dim3(G::THREADS), G::LDS_BYTES, s,
+                     (const _Float16 *)p.a, (const _Float16 *)p.b, (_Float16 *)p.c, p.n, p.k, p.m, tiles_n, tiles_m);
+  return (int)hipGetLastError();
+}
+
+}  // namespace mm

@@ -70,6 +70,47 @@ def test_f32_mfma_transpose_detecting_inputs():
     assert np.array_equal(c, (a.astype(np.float64) @ b.astype(np.float64)).astype(np.float32))
 
 
+@pytest.mark.parametrize("shape", [(513, 528, 528), (1, 16, 8), (37, 32, 48), (300, 64, 272), (129, 80, 264), (257, 1040, 520)],
+                         ids=lambda s: "x".join(map(str, s)))
+def test_f64_mfma_vs_blas(shape):
+    n, k, m = shape
+    a, b = _oracle.fill("double", n, k, m)
+    assert g.kernel_name(g.make_config("double"), n, k, m) == "mfma_f64"
+    c, _ = g.matmul_capi(a, b, "double")
+    bad, first, worst = _oracle.compare("double", c, a @ b, 1e-12)  # numpy float64 matmul == cblas_dgemm
+    assert bad == 0, (first, worst)
+    assert np.array_equal(c, _oracle.naive("double", "Multiply", "Add", a, b)) or worst < 1e-13
+
+
+@pytest.mark.parametrize("shape", [(513, 528, 528), (1, 16, 8), (37, 32, 48), (300, 64, 272), (129, 80, 264), (257, 1040, 520)],
+                         ids=lambda s: "x".join(map(str, s)))
+def test_f16_mfma_wide_accumulate_contract(shape):
+    """half: exact products, f32 accumulation, ONE rounding on store.  Against the
+    oracle's wide-accumulate Naive (double accumulation, one rounding) it may differ by at most
+    one binary16 ulp; against the exact value by one rounding + the f32 accumulation error."""
+    n, k, m = shape
+    a, b = _oracle.fill("half", n, k, m)
+    assert g.kernel_name(g.make_config("half"), n, k, m) == "mfma_f16"
+    c, _ = g.matmul_capi(a, b, "half")
+    wide = _oracle.naive("half", "Multiply", "Add", a, b, wide_half=True)
+    exact = a.astype(np.float64) @ b.astype(np.float64)
+    assert np.all(np.isfinite(c.astype(np.float64)) == np.isfinite(wide.astype(np.float64)))
+    fin = np.isfinite(wide.astype(np.float64))
+    ulps = np.abs(c.view(np.int16).astype(np.int32) - wide.view(np.int16).astype(np.int32))[fin]
+    assert ulps.max() <= 1, ulps.max()
+    assert (ulps != 0).mean() < 0.02          # and it is rare
+    rel = np.abs(c.astype(np.float64) - exact)[fin] / exact[fin]
+    assert rel.max() <= 2.0 ** -11 * 1.01      # half an ulp of binary16 relative to the exact value (+f32 noise)
+
+
+def test_f16_overflow_behaviour_matches_ieee():
+    # K large enough that sums pass 65504: binary16 result is +inf, like a correctly rounded result
+    n, k, m = 33, 4096, 64
+    a, b = _oracle.fill("half", n, k, m)
+    c, _ = g.matmul_capi(a, b, "half")
+    assert np.all(np.isinf(c.astype(np.float32)))
+
+
 ORDERED_CASES = [
     ("float", "Multiply", "Add"), ("float", "Add", "Min"), ("float", "Add", "Max"), ("float", "Min", "Max"),
     ("double", "Multiply", "Add"), ("half", "Multiply", "Add"), ("int", "Multiply", "Add"), ("int", "Add", "Min"),
