@@ -1,0 +1,149 @@
+"""CPU model of the LDS images of the MFMA kernels (no GPU needed): for every fragment read it
+enumerates the lanes of each hardware service group and checks that
+  * DMA-write (lane-linear destination, permuted SOURCE) followed by the fragment read returns the
+    matrix element the MFMA operand needs (the permutation pair is an involution), and
+  * every ds_read_b128 service group touches 16 distinct 16-byte slots of the 256-byte bank row
+    (MI355X_MICROARCH.md, LDS table: b128 is served in 4 groups of 16 lanes, bank = (addr/4) % 64).
+The formulas are the ones in gemm_hls_amd/csrc/mm_mfma_{f32,f64,f16}.hip."""
+import itertools
+
+import pytest
+
+B128_GROUPS = [
+    [0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27],
+    [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31],
+    [32, 33, 34, 35, 44, 45, 46, 47, 52, 53, 54, 55, 56, 57, 58, 59],
+    [36, 37, 38, 39, 40, 41, 42, 43, 48, 49, 50, 51, 60, 61, 62, 63],
+]
+
+
+def slots16(addrs):
+    """16-byte slot index inside the 256-byte bank row for each byte address."""
+    return [(a // 16) % 16 for a in addrs]
+
+
+def assert_conflict_free_b128(addr_of_lane):
+    for grp in B128_GROUPS:
+        s = slots16([addr_of_lane(l) for l in grp])
+        assert len(set(s)) == 16, (grp, s)
+
+
+# ---------------------------------------------------------------- fp32 A / B images ------------
+@pytest.mark.parametrize("BK", [16, 32])
+def test_f32_a_image_roundtrip_and_banks(BK):
+    CPR = BK // 4
+    SH = 2 if CPR == 4 else 1
+    BM = 128
+    # DMA: slot s (16 B) <- A[row = s // CPR][logical chunk = (s % CPR) ^ swz(row)]
+    lds = {}
+    for s in range(BM * CPR):
+        row, pc = divmod(s, CPR)
+        lc = pc ^ ((row >> SH) & (CPR - 1))
+        lds[s * 16] = (row, lc)  # what lives at this byte address
+    for wm_rows, mi, kg in itertools.product([0, 64], [0, 1], range(BK // 8)):
+        def addr(l):
+            lo, hi = l & 31, l >> 5
+            a_swz = hi ^ ((lo >> SH) & (CPR - 1))
+            return (wm_rows + lo) * BK * 4 + mi * 32 * BK * 4 + ((2 * kg) ^ a_swz) * 16
+        for l in range(64):
+            row, lc = lds[addr(l)]
+            assert row == wm_rows + mi * 32 + (l & 31)
+            assert lc == 2 * kg + (l >> 5)           # k = 8*kg + 4*(lane>>5) + 0..3
+        assert_conflict_free_b128(addr)
+
+
+def test_f32_b_image_banks():
+    BN = 256
+    for kg, p, wn in itertools.product(range(4), range(4), range(2)):
+        def addr(l):
+            lo, hi = l & 31, l >> 5
+            return (4 * hi) * BN * 4 + (wn * 128 + 4 * lo) * 4 + (kg * 8 + p) * BN * 4
+        assert_conflict_free_b128(addr)
+        for l in range(64):  # element addressed = B[k][col] row-major, untouched by the DMA
+            k, col = divmod(addr(l) // 4, BN)
+            assert k == kg * 8 + p + 4 * (l >> 5) and col == wn * 128 + 4 * (l & 31)
+
+
+def test_f32_accumulation_covers_every_k_once():
+    # inside an 8-deep group MFMA p multiplies k = p (lanes < 32) and k = p + 4 (lanes >= 32)
+    ks = sorted(p + 4 * hi for p in range(4) for hi in range(2))
+    assert ks == list(range(8))
+
+
+# ---------------------------------------------------------------- fp64 -------------------------
+def test_f64_a_image_roundtrip_and_banks():
+    CPR, BK, BM = 8, 16, 256
+    lds = {}
+    for s in range(BM * CPR):
+        row, pc = divmod(s, CPR)
+        lds[s * 16] = (row, pc ^ ((row >> 1) & 7))
+    for wm, mi, kg in itertools.product(range(4), range(4), range(2)):
+        def addr(l):
+            lo, g4 = l & 15, l >> 4
+            a_swz = (lo >> 1) & 7
+            return (wm * 64 + lo) * BK * 8 + mi * 16 * BK * 8 + (((4 * kg) + g4) ^ a_swz) * 16
+        for l in range(64):
+            row, lc = lds[addr(l)]
+            assert row == wm * 64 + mi * 16 + (l & 15)
+            assert lc == 4 * kg + (l >> 4)           # doubles 2*lc, 2*lc+1 -> k = 8kg + 2*g4 + p
+        assert_conflict_free_b128(addr)
+
+
+def test_f64_b_image_banks():
+    BN = 128
+    for kg, p, pr, wn in itertools.product(range(2), range(2), range(2), range(2)):
+        def addr(l):
+            lo, g4 = l & 15, l >> 4
+            return (2 * g4) * BN * 8 + (wn * 64 + 2 * lo) * 8 + (kg * 8 + p) * BN * 8 + pr * 32 * 8
+        assert_conflict_free_b128(addr)
+        for l in range(64):
+            k, col = divmod(addr(l) // 8, BN)
+            assert k == kg * 8 + 2 * (l >> 4) + p and col == wn * 64 + pr * 32 + 2 * (l & 15)
+    assert sorted(2 * g + p for p in range(2) for g in range(4)) == list(range(8))
+
+
+# ---------------------------------------------------------------- fp16 B (transpose reads) ------
+def test_f16_b_image_transpose_read_gather_and_banks():
+    BN, BROW, BCH = 256, 512, 32
+    # DMA: slot -> (k row, physical chunk); holds logical chunk pc ^ ((k&3)<<2)
+    lds = {}
+    for kr in range(64):
+        for pc in range(BCH):
+            lds[kr * BROW + pc * 16] = (kr, pc ^ ((kr & 3) << 2))
+
+    def element_at(byte_addr):  # (k, column) of the half stored at this LDS byte address
+        base = (byte_addr // 16) * 16
+        kr, lc = lds[base]
+        return kr, lc * 8 + (byte_addr - base) // 2
+
+    for ks, h, ni, wn in itertools.product(range(4), range(2), range(4), range(2)):
+        def addr(l):
+            x, gq, hi = l & 15, (l >> 4) & 1, l >> 5
+            r = x >> 2
+            lane_base = (8 * hi + r) * BROW + (wn * 16 + 2 * gq + ((x & 3) >> 1)) * 16 + (x & 1) * 8
+            return lane_base + (ni ^ r) * 64 + ks * 16 * BROW + h * 4 * BROW
+        # hardware transpose inside each 16-lane group: out[i][j] = in[4j + (i>>2)][i&3]
+        for l in range(64):
+            i, grp = l & 15, l & ~15
+            for j in range(4):
+                src_lane = grp + 4 * j + (i >> 2)
+                k, col = element_at(addr(src_lane) + 2 * (i & 3))
+                assert k == ks * 16 + 8 * (l >> 5) + 4 * h + j
+                assert col == wn * 128 + ni * 32 + (l & 31)
+        # b64 reads are served per 32-lane half, bank = (addr/4) % 64: 32 lanes x 8 B must be disjoint
+        for half in (range(0, 32), range(32, 64)):
+            banks = set()
+            for l in half:
+                for d in (0, 4):
+                    banks.add(((addr(l) + d) // 4) % 64)
+            assert len(banks) == 64
+
+
+def test_xcd_remap_is_a_bijection():
+    def remap(bid, nwg):
+        q, r = divmod(nwg, 8)
+        xcd, slot = bid % 8, bid // 8
+        base = xcd * (q + 1) if xcd < r else r * (q + 1) + (xcd - r) * q
+        return base + slot
+    for nwg in [1, 7, 8, 9, 63, 64, 65, 1000, 8192, 8191]:
+        assert sorted(remap(b, nwg) for b in range(nwg)) == list(range(nwg))

@@ -1,0 +1,74 @@
+"""The N>1 path on CPU: world_size-2 `gloo` processes (no GPU here).  The data path of the
+multi-GPU design has no collective (rows of C are split, B replicated); what runs across ranks is
+the row partition, the barrier and the max-over-ranks timing of bench.py.  Each rank multiplies
+its own slab -- with the CPU oracle standing in for the device, which is fine for a test of the
+partition -- and rank 0 checks that the stacked slabs equal the unsplit product bit for bit."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from gemm_hls_amd.partition import row_slab  # noqa: E402
+
+
+@pytest.mark.parametrize("n,world", [(16384, 8), (65536, 8), (513, 2), (5, 8), (1, 4), (256, 3)])
+def test_row_slabs_tile_the_rows(n, world):
+    covered = []
+    for r in range(world):
+        row0, rows = row_slab(n, world, r)
+        assert 0 <= rows and row0 + rows <= n
+        covered.extend(range(row0, row0 + rows))
+    assert covered == list(range(n))
+    assert max(row_slab(n, world, r)[1] for r in range(world)) == -(-n // world)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, dtype, ops, shape, out_dir):
+    import torch
+    import torch.distributed as dist
+    import _oracle
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n, k, m = shape
+    a, b = _oracle.fill(dtype, n, k, m)          # every rank regenerates the seeded inputs
+    row0, rows = row_slab(n, world, rank)
+    c_slab = _oracle.naive(dtype, ops[0], ops[1], a[row0:row0 + rows], b, threads=1) if rows else \
+        np.empty((0, m), a.dtype)
+    # bench.py's timing protocol: barrier, local time, MAX over ranks
+    dist.barrier()
+    t = torch.tensor([0.25 + rank], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    assert float(t) == 0.25 + world - 1
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (row0, rows, c_slab.tobytes()))
+    if rank == 0:
+        full = _oracle.naive(dtype, ops[0], ops[1], a, b, threads=1)
+        stacked = b"".join(g[2] for g in sorted(gathered))
+        ok = stacked == full.tobytes() and sum(g[1] for g in gathered) == n
+        open(os.path.join(out_dir, "ok"), "w").write("1" if ok else "0")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("dtype,ops,shape", [("float", ("Multiply", "Add"), (37, 32, 48)),
+                                             ("int", ("Multiply", "Add"), (5, 16, 16)),
+                                             ("float", ("Add", "Min"), (64, 16, 32))])
+def test_world_size_2_row_split_reproduces_unsplit_product(tmp_path, dtype, ops, shape):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.start_processes(_worker, args=(2, port, dtype, ops, shape, str(tmp_path)), nprocs=2, join=True,
+                       start_method="spawn")
+    assert open(tmp_path / "ok").read() == "1"
