@@ -22,7 +22,7 @@ PATH_AUTO, PATH_ORDERED = 0, 1
 EXPORTS = ["mm_init", "mm_alloc", "mm_free", "mm_copy_to_device", "mm_copy_to_host",
            "mm_fill_device", "mm_gemm_launch", "mm_gemm_enqueue", "mm_gemm_multi_device",
            "MatrixMultiplicationKernel", "mm_set_default_config", "mm_dtype_size",
-           "mm_config_supported", "mm_kernel_name", "mm_last_error"]
+           "mm_config_supported", "mm_kernel_name", "mm_kernel_info", "mm_last_error"]
 
 
 class MMError(RuntimeError):

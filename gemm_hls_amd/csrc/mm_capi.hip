@@ -80,7 +80,9 @@ int f32_variant() {
   static int cached = -2;
   const char *e = getenv("MM_F32_VARIANT");  // tuning hook for bench sweeps; re-read each call
   if (e && *e) return atoi(e);
-  if (cached == -2) cached = 0;
+  // default: 256x256x16, 8 wavefronts, accumulators flushed into C every 4096 k
+  // (145 TF at 16384^3, max rel err 2.7e-6 over the full matrix: profiles/r01_f32_precision_full_matrix.txt)
+  if (cached == -2) cached = 8;
   return cached;
 }
 
@@ -331,6 +333,49 @@ const char *mm_kernel_name(const mm_config_t *cfg, unsigned n, unsigned k, unsig
     case FAM_VALU_TILE: return "valu_tile";
     default: return "ordered";
   }
+}
+
+int mm_kernel_info(const mm_config_t *cfg, unsigned n, unsigned k, unsigned m, mm_kernel_info_t *info) {
+  if (!valid_cfg(cfg) || !info) return fail(MM_ERR_BAD_ARGUMENT, "invalid arguments to mm_kernel_info");
+  mm::Problem p{nullptr, nullptr, nullptr, n, k, m, cfg->layout_a == MM_A_TRANSPOSED};
+  mm_kernel_info_t r = {};
+  r.compute_units = 256;
+  r.max_clock_mhz = 2400.0;
+  switch (choose(*cfg, p)) {
+    case FAM_MFMA_F32:
+      mm::mfma_f32_geometry(f32_variant(), &r.tile_n, &r.tile_m, &r.tile_k, &r.wavefronts);
+      r.inst_n = 32; r.inst_m = 32; r.inst_k = 2; r.ops_per_clk_per_cu = 256.0;   // 64 FLOP/clk/SIMD
+      r.measured_issue_efficiency = 0.934;  // profiles/r01_pmc_f32_default.json
+      break;
+    case FAM_MFMA_F64:
+      r.tile_n = 256; r.tile_m = 128; r.tile_k = 16; r.wavefronts = 8;
+      r.inst_n = 16; r.inst_m = 16; r.inst_k = 4; r.ops_per_clk_per_cu = 128.0;
+      r.measured_issue_efficiency = 0.92;
+      break;
+    case FAM_MFMA_F16:
+      r.tile_n = 256; r.tile_m = 256; r.tile_k = 64; r.wavefronts = 8;
+      r.inst_n = 32; r.inst_m = 32; r.inst_k = 16; r.ops_per_clk_per_cu = 4096.0;
+      r.measured_issue_efficiency = 0.60;   // profiles/r01_pmc_f16.json (and the clock drops to ~1.7 GHz)
+      break;
+    case FAM_VALU_TILE: {
+      r.tile_n = 128; r.tile_m = 128; r.tile_k = 16; r.wavefronts = 4;
+      r.inst_n = 1; r.inst_m = 64; r.inst_k = 1;
+      // 128 lane-instructions per clock per CU; a map+reduce step (2 ops) costs 2 instructions,
+      // 1 when it fuses (float multiply-add), 1.5 for float min/max reductions (v_min3/v_max3)
+      const bool fp = cfg->dtype == MM_DTYPE_F32 || cfg->dtype == MM_DTYPE_F16;
+      const bool fma = cfg->map_op == MM_OP_MULTIPLY && cfg->reduce_op == MM_OP_ADD && (fp || cfg->dtype == MM_DTYPE_F64);
+      const bool m3 = fp && (cfg->reduce_op == MM_OP_MIN || cfg->reduce_op == MM_OP_MAX);
+      r.ops_per_clk_per_cu = fma ? 256.0 : (m3 ? 128.0 * 4.0 / 3.0 : 128.0);
+      r.measured_issue_efficiency = 0.65;
+      break;
+    }
+    default:
+      r.tile_n = 64; r.tile_m = 64; r.tile_k = 16; r.wavefronts = 4;
+      r.inst_n = 1; r.inst_m = 64; r.inst_k = 1; r.ops_per_clk_per_cu = 128.0;
+      break;
+  }
+  *info = r;
+  return MM_OK;
 }
 
 }  // extern "C"

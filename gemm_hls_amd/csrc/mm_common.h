@@ -85,6 +85,7 @@ bool mfma_f32_serves(const Problem &p);
 bool mfma_f64_serves(const Problem &p);
 bool mfma_f16_serves(const Problem &p);
 const char *mfma_f32_name(int variant);
+void mfma_f32_geometry(int variant, unsigned *bm, unsigned *bn, unsigned *bk, unsigned *waves);
 int mfma_f32_num_variants();
 int launch_fill(hipStream_t s, mm_dtype_t dtype, void *ptr, size_t elements, unsigned long long seed);
 

@@ -36,6 +36,13 @@
 // products drifts to ~1e-5 relative in the worst element; with 512-deep chunks
 // the worst case stays < 1e-6, inside BASELINE.json's 1e-5 bar with margin.
 //
+// Chunked flush (FC > 0): the other way to bound the chain length, for geometries whose register
+// file has no room for a second accumulator set (8 wavefronts of 64x128, 2 per SIMD): every FC
+// slabs the workgroup adds its accumulators into its own C tile in HBM (first chunk: plain store)
+// and restarts them from zero.  The same workgroup owns the tile for the whole launch, so the
+// read-modify-write is race-free and deterministic; it costs one extra read+write of C per chunk
+// (K/(FC*BK) - 1 times 2 x N*M*4 bytes, mostly served by the Infinity Cache).
+//
 // Edges: N arbitrary (row indices clamped for loads, stores predicated); M % 4 == 0 (column
 // chunks clamped / predicated); K % 8 == 0 (a partial last slab is consumed in 8-deep groups;
 // the DMA of its unused part is clamped to valid addresses and never read).  Everything else is
@@ -50,9 +57,10 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 typedef const __attribute__((address_space(1))) void *gptr_t;
 typedef __attribute__((address_space(3))) void *lptr_t;
 
-template <int TM_, int WM_, int WN_, int BK_, int NS_, bool TWO_LEVEL_, int KC_>
+template <int TM_, int WM_, int WN_, int BK_, int NS_, bool TWO_LEVEL_, int KC_, int FC_ = 0>
 struct Geo {
   static constexpr int TM = TM_, WM = WM_, WN = WN_, BK = BK_, NS = NS_, KC = KC_;
+  static constexpr int FC = FC_;  // > 0: flush the accumulators into C every FC slabs (see below)
   static constexpr bool TWO_LEVEL = TWO_LEVEL_;
   static constexpr int TN = 4;                       // 4 accumulators x 32 = 128 columns per wave
   static constexpr int NW = WM * WN;                 // wavefronts per workgroup
@@ -172,6 +180,28 @@ __global__ __launch_bounds__(G::THREADS) void mfma_f32_kernel(const float *__res
           acc[mi][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi][p], bf[p][t], acc[mi][t], 0, 0, 0);
   };
 
+  // C (+)= accumulators; accumulators = 0   (chunked flush, FC > 0 only)
+  auto flush_tile = [&](bool accumulate) {
+    const unsigned ccol = col0 + wn * 128 + 4 * lo;
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const unsigned row = row0 + wm * TM * 32 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        if (ccol < M && row < N) {
+          f32x4 *dst = (f32x4 *)(C + (size_t)row * M + ccol);
+          f32x4 v;
+#pragma unroll
+          for (int tt = 0; tt < TN; ++tt) v[tt] = acc[mi][tt][r];
+          if (accumulate) v += *dst;
+          *dst = v;
+        }
+      }
+#pragma unroll
+      for (int tt = 0; tt < TN; ++tt) acc[mi][tt] = (f32x16)0.0f;
+    }
+  };
+
   const unsigned num_tiles = (K + BK - 1) / BK;   // slabs, the last one possibly partial
   constexpr int L = G::LA + G::LB;                // DMA instructions per wavefront per slab
 
@@ -215,7 +245,19 @@ __global__ __launch_bounds__(G::THREADS) void mfma_f32_kernel(const float *__res
   };
 
   const unsigned steady = num_tiles - 1;  // slabs 0 .. num_tiles-2 are full and have a successor
-  if (G::TWO_LEVEL) {
+  bool flushed = false;
+  if (G::FC > 0) {
+    for (unsigned t0 = 0; t0 < steady; t0 += G::FC) {
+      const unsigned tend = min(t0 + (unsigned)G::FC, steady);
+      for (unsigned t = t0; t < tend; ++t) slab(t);
+      if (tend < steady) {  // a further chunk follows: C (+)= acc, restart the chain
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        flush_tile(flushed);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        flushed = true;
+      }
+    }
+  } else if (G::TWO_LEVEL) {
     for (unsigned t0 = 0; t0 < steady; t0 += G::KC) {
       const unsigned tend = min(t0 + (unsigned)G::KC, steady);
       for (unsigned t = t0; t < tend; ++t) slab(t);
@@ -245,27 +287,32 @@ __global__ __launch_bounds__(G::THREADS) void mfma_f32_kernel(const float *__res
   // wave can retire and its workgroup's LDS allocation can be handed to another workgroup.
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-  // ---- epilogue: lane owns 4 consecutive columns of 16 rows per accumulator row-block --------
-  const unsigned ccol = col0 + wn * 128 + 4 * lo;
-  if (ccol < M) {
+  // ---- tile write: lane owns 4 consecutive columns of 16 rows per accumulator row-block --------
+  auto write_tile = [&](bool accumulate) {
+    const unsigned ccol = col0 + wn * 128 + 4 * lo;
+    if (ccol < M) {
 #pragma unroll
-    for (int mi = 0; mi < TM; ++mi) {
+      for (int mi = 0; mi < TM; ++mi) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const unsigned row = row0 + wm * TM * 32 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        if (row < N) {
-          f32x4 v;
+        for (int r = 0; r < 16; ++r) {
+          const unsigned row = row0 + wm * TM * 32 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          if (row < N) {
+            f32x4 *dst = (f32x4 *)(C + (size_t)row * M + ccol);
+            f32x4 v;
 #pragma unroll
-          for (int tt = 0; tt < TN; ++tt) {
-            float x = acc[mi][tt][r];
-            if (G::TWO_LEVEL) x += master[mi][tt][r];
-            v[tt] = x;
+            for (int tt = 0; tt < TN; ++tt) {
+              float x = acc[mi][tt][r];
+              if (G::TWO_LEVEL) x += master[mi][tt][r];
+              v[tt] = x;
+            }
+            if (accumulate) v += *dst;
+            *dst = v;
           }
-          *(f32x4 *)(C + (size_t)row * M + ccol) = v;
         }
       }
     }
-  }
+  };
+  if (G::FC > 0 && flushed) write_tile(true); else write_tile(false);
 }
 
 template <typename G>
@@ -287,10 +334,13 @@ using V4 = Geo<2, 2, 2, 32, 3, true, 16>;    // V0 with a 3-deep ring and counte
 using V5 = Geo<2, 2, 2, 16, 2, true, 32>;    // V0 with BK = 16
 using V6 = Geo<4, 2, 2, 16, 3, false, 1>;    // V2 with a 3-deep ring
 using V7 = Geo<1, 4, 2, 32, 2, true, 16>;    // 128x256, 8 waves, 32x128 per wave
+using V8 = Geo<2, 4, 2, 16, 2, false, 1, 256>;  // V3 + flush into C every 4096 k
+using V9 = Geo<2, 4, 2, 16, 2, false, 1, 128>;  // V3 + flush into C every 2048 k
+using V10 = Geo<2, 4, 2, 32, 2, false, 1, 128>; // 256x256x32, 8 waves (144 KiB LDS), flush every 4096 k
 
 }  // namespace
 
-int mfma_f32_num_variants() { return 8; }
+int mfma_f32_num_variants() { return 11; }
 
 const char *mfma_f32_name(int v) {
   switch (v) {
@@ -302,8 +352,30 @@ const char *mfma_f32_name(int v) {
     case 5: return "mfma_f32_128x256x16_w4_2lvl";
     case 6: return "mfma_f32_256x256x16_w4_ns3";
     case 7: return "mfma_f32_128x256x32_w8_2lvl";
+    case 8: return "mfma_f32_256x256x16_w8_flush4096";
+    case 9: return "mfma_f32_256x256x16_w8_flush2048";
+    case 10: return "mfma_f32_256x256x32_w8_flush4096";
   }
   return "?";
+}
+
+template <typename G> static void geo_of(unsigned *bm, unsigned *bn, unsigned *bk, unsigned *waves) {
+  *bm = G::BM; *bn = G::BN; *bk = G::BK; *waves = G::NW;
+}
+void mfma_f32_geometry(int v, unsigned *bm, unsigned *bn, unsigned *bk, unsigned *waves) {
+  switch (v) {
+    case 0: return geo_of<V0>(bm, bn, bk, waves);
+    case 1: return geo_of<V1>(bm, bn, bk, waves);
+    case 2: return geo_of<V2>(bm, bn, bk, waves);
+    case 3: return geo_of<V3>(bm, bn, bk, waves);
+    case 4: return geo_of<V4>(bm, bn, bk, waves);
+    case 5: return geo_of<V5>(bm, bn, bk, waves);
+    case 6: return geo_of<V6>(bm, bn, bk, waves);
+    case 7: return geo_of<V7>(bm, bn, bk, waves);
+    case 9: return geo_of<V9>(bm, bn, bk, waves);
+    case 10: return geo_of<V10>(bm, bn, bk, waves);
+    default: return geo_of<V8>(bm, bn, bk, waves);
+  }
 }
 
 bool mfma_f32_serves(const Problem &p) {
@@ -321,6 +393,9 @@ int launch_mfma_f32(hipStream_t s, const Problem &p, int variant) {
     case 5: return launch_geo<V5>(s, p);
     case 6: return launch_geo<V6>(s, p);
     case 7: return launch_geo<V7>(s, p);
+    case 8: return launch_geo<V8>(s, p);
+    case 9: return launch_geo<V9>(s, p);
+    case 10: return launch_geo<V10>(s, p);
   }
   return kErrNotSupported;
 }

@@ -145,6 +145,21 @@ int mm_config_supported(const mm_config_t *cfg);
 /* Name of the kernel family that mm_gemm_launch would run for this problem (static string),
  * e.g. "mfma_f32_128x256x32", "valu_tile", "ordered". */
 const char *mm_kernel_name(const mm_config_t *cfg, unsigned size_n, unsigned size_k, unsigned size_m);
+/* Geometry of the kernel family that would serve this problem: the GPU counterpart of the
+ * constants src/PrintSpecifications.cpp prints for the FPGA build (memory tile = the output tile a
+ * workgroup keeps resident, compute tile = what one wavefront instruction computes). */
+typedef struct {
+  unsigned tile_n, tile_m, tile_k;     /* resident C tile (rows x cols) and k-slab per workgroup  */
+  unsigned wavefronts;                 /* wavefronts per workgroup                               */
+  unsigned inst_n, inst_m, inst_k;     /* shape of one matrix/vector instruction (1x64x1 = VALU) */
+  double ops_per_clk_per_cu;           /* peak map+reduce operations per clock per compute unit  */
+  unsigned compute_units;              /* 256 on MI355X                                          */
+  double max_clock_mhz;                /* 2400 on MI355X                                         */
+  double measured_issue_efficiency;    /* fraction of issue slots the family sustains at BASELINE
+                                          size (rocprofv3 MfmaUtil, profiles/), 0 if not measured */
+} mm_kernel_info_t;
+int mm_kernel_info(const mm_config_t *cfg, unsigned size_n, unsigned size_k, unsigned size_m,
+                   mm_kernel_info_t *info);
 /* Message of the last failing call on this thread (static or thread-local storage). */
 const char *mm_last_error(void);
 

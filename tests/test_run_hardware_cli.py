@@ -100,3 +100,37 @@ def test_run_hardware_timing_only_and_report_format():
 def test_run_hardware_multi_gpu_env_single_device():
     r = run(EXE, 300, 64, 272, "hw", "on", env={"MM_GPUS": "1"})
     assert r.returncode == 0 and "Successfully verified." in r.stdout
+
+
+# ---- the other two host binaries of the reference: TestSimulation, PrintSpecifications ---------
+def test_print_specifications_cli_and_model():
+    exe = os.path.join(ROOT, "bin", "PrintSpecifications.exe")
+    r = run(exe, 16384, 16384)
+    assert r.returncode == 1 and "N K M [<routed_frequency>]" in r.stderr
+    r = run(exe, 16384, 16384, 16384)
+    assert r.returncode == 0
+    out = r.stdout
+    assert "Number of operations: 8796093022208" in out            # 2*N*K*M (src/PrintSpecifications.cpp:40-41)
+    assert "Ideal performance:    157286 GOp/s" in out              # 256 CU x 256 FLOP/clk x 2.4 GHz
+    assert "Memory tile size: 256x256" in out and "Frequency:            2400 MHz" in out
+    comm = int(re.search(r"Communication volume: (\d+)", out).group(1))
+    assert comm == 16384 * 16384 * (1 + 16384 // 256 + 16384 // 256)  # N*M*(1 + K/TN + K/TM), :72-74
+    r2 = run(exe, 16384, 16384, 16384, 1200)
+    assert "Ideal performance:    78643" in r2.stdout               # scales with the routed frequency
+
+
+def test_test_simulation_cli_errors():
+    exe = os.path.join(ROOT, "bin", "TestSimulation.exe")
+    assert run(exe).returncode == 1 and "Usage: ./TestSimulation N K M" in run(exe).stderr
+    r = run(exe, 64, 17, 64)
+    assert r.returncode == 1 and "K must be divisable by memory width." in r.stderr
+    r = run(exe, 64, 16, 17)
+    assert r.returncode == 1 and "M must be divisable by memory width." in r.stderr
+
+
+@pytest.mark.gpu
+def test_test_simulation_reference_ctest_shape_on_gpu():
+    """The reference's CTest: TestSimulation 513 528 528 (CMakeLists.txt:155-159)."""
+    r = run(os.path.join(ROOT, "bin", "TestSimulation.exe"), 513, 528, 528)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "Running simulation..." in r.stdout and "Matrix-matrix multiplication successfully verified." in r.stdout

@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""MFMA utilisation, effective clock, wait breakdown, LDS conflicts and L2 hit rate of a kernel
+family from rocprofv3 PMC passes (each pass only --pmc + --kernel-trace, as gpurun requires).
+  python tools/pmc_mfma.py f32|f64|f16|minplus [--size 16384] [--out profiles/r01_pmc_f32.json]
+MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * 1024 SIMDs); effective clock =
+GRBM_GUI_ACTIVE / kernel duration (MI355X_MICROARCH.md, DVFS note)."""
+import argparse
+import csv
+import glob
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PASSES = [
+    ["SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES"],
+    ["SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE"],
+    ["TCC_HIT_sum", "TCC_MISS_sum"],
+]
+KERNEL = {"f32": "mfma_f32_kernel", "f64": "mfma_f64_kernel", "f16": "mfma_f16_kernel", "minplus": "valu_tile_kernel"}
+
+
+def run_pass(counters, what, size, workdir, idx):
+    d = os.path.join(workdir, f"pass{idx}")
+    shutil.rmtree(d, ignore_errors=True)
+    os.makedirs(d, exist_ok=True)
+    cmd = ["rocprofv3", "--pmc", *counters, "--kernel-trace", "-d", d, "-o", "pmc", "--output-format", "csv", "--",
+           sys.executable, os.path.join(ROOT, "tools", "sweep.py"), what, "--sizes", str(size), "--reps", "3"]
+    if what == "f32" and os.environ.get("MM_F32_VARIANT"):
+        cmd += ["--variants", os.environ["MM_F32_VARIANT"]]
+    elif what == "f32":
+        cmd += ["--variants", "8"]
+    r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(r.stdout[-1500:] + r.stderr[-1500:])
+        raise SystemExit("rocprofv3 pass failed: " + " ".join(counters))
+    vals, durs = {}, []
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            if KERNEL[what] in row.get("Kernel_Name", ""):
+                vals.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+    for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            if KERNEL[what] in row.get("Kernel_Name", ""):
+                durs.append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+    out = {k: sum(v) / len(v) for k, v in vals.items()}
+    out["_duration_ns"] = sum(durs) / max(1, len(durs))
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("what", choices=list(KERNEL))
+    ap.add_argument("--size", type=int, default=16384)
+    ap.add_argument("--out", default=None)
+    ap.add_argument("--workdir", default=os.path.join(ROOT, "gpurun_out", "pmc_mfma"))
+    args = ap.parse_args()
+    res = {"kernel": KERNEL[args.what], "size": args.size, "passes": []}
+    flat = {}
+    for i, p in enumerate(PASSES):
+        r = run_pass(p, args.what, args.size, os.path.join(args.workdir, args.what), i)
+        res["passes"].append(r)
+        flat.update(r)
+    simds = 1024
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in flat and flat.get("GRBM_GUI_ACTIVE"):
+        gui = flat["GRBM_GUI_ACTIVE"] / 8.0  # rocprofv3 reports the sum over the 8 XCDs
+        res["GRBM_GUI_ACTIVE_per_XCD"] = gui
+        res["MfmaUtil_pct"] = 100.0 * flat["SQ_VALU_MFMA_BUSY_CYCLES"] / (gui * simds)
+        res["effective_clock_GHz_profiled"] = gui / res["passes"][0]["_duration_ns"]
+    if flat.get("TCC_HIT_sum") is not None and flat.get("TCC_MISS_sum") is not None:
+        res["L2_hit_rate"] = flat["TCC_HIT_sum"] / max(1.0, flat["TCC_HIT_sum"] + flat["TCC_MISS_sum"])
+    if flat.get("SQ_WAVE_CYCLES"):
+        for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_LDS"):
+            if k in flat:
+                res[k + "_over_WAVE_CYCLES"] = flat[k] / flat["SQ_WAVE_CYCLES"]
+    out = args.out or os.path.join(ROOT, "gpurun_out", f"pmc_{args.what}.json")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    json.dump(res, open(out, "w"), indent=1)
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()
