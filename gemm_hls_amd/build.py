@@ -95,6 +95,14 @@ def build(verbose=True):
                                   f"-DMM_DATA_TYPE={dt}", f"-DMM_MAP_OP={mp}", f"-DMM_REDUCE_OP={rd}",
                                   "-DMM_DYNAMIC_SIZES", "-I" + os.path.join(ROOT, "include"), "-I" + host_dir,
                                   src, "-o", out, "-L" + HERE, "-lmm_gemm_amd", rpath, "-ldl"])
+    # static-size build (MM_DYNAMIC_SIZES=OFF, CMakeLists.txt:21-24): sizes baked in, argv = [mode] [verify]
+    src = os.path.join(host_dir, "RunHardware.cpp")
+    out = os.path.join(BIN, "RunHardware_static_float_528x512x560.exe")
+    if os.path.exists(src) and newer(out, [src, LIB] + host_hdrs + [__file__]):
+        host_jobs.append(["/opt/rocm/lib/llvm/bin/clang++", "-O2", "-std=c++17", "-pthread", "-DMM_DATA_TYPE=float",
+                          "-DMM_MAP_OP=Multiply", "-DMM_REDUCE_OP=Add", "-DMM_SIZE_N=528", "-DMM_SIZE_K=512",
+                          "-DMM_SIZE_M=560", "-I" + os.path.join(ROOT, "include"), "-I" + host_dir, src, "-o", out,
+                          "-L" + HERE, "-lmm_gemm_amd", rpath, "-ldl"])
     for extra in ("PrintSpecifications", "TestSimulation"):
         src = os.path.join(host_dir, extra + ".cpp")
         out = os.path.join(BIN, extra + ".exe")

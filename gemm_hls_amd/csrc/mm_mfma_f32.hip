@@ -79,7 +79,7 @@ struct Geo {
   static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 };
 
-template <typename G>
+template <typename G, bool AT>
 __global__ __launch_bounds__(G::THREADS) void mfma_f32_kernel(const float *__restrict__ A,
                                                               const float *__restrict__ B,
                                                               float *__restrict__ C, unsigned N,
@@ -110,9 +110,16 @@ __global__ __launch_bounds__(G::THREADS) void mfma_f32_kernel(const float *__res
 #pragma unroll
   for (int i = 0; i < G::LA; ++i) {
     const unsigned slot = (wave + G::NW * i) * 64 + lane;
-    const unsigned row = slot / CPR, pc = slot % CPR;
-    a_kchunk[i] = pc ^ ((row >> G::SWZ_SHIFT) & (CPR - 1));
-    a_row_off[i] = (size_t)min(row0 + row, N - 1) * K;
+    if (AT) {
+      // A stored K x N (MM_TRANSPOSED_A, kernel/Memory.cpp:205-228): the slab is [BK][BM] like B's,
+      // a k-row of the tile is contiguous in memory; a_kchunk = k-row, a_row_off = column offset.
+      a_kchunk[i] = slot / (G::BM / 4);
+      a_row_off[i] = min(row0 + (slot % (G::BM / 4)) * 4, N - 4);
+    } else {
+      const unsigned row = slot / CPR, pc = slot % CPR;
+      a_kchunk[i] = pc ^ ((row >> G::SWZ_SHIFT) & (CPR - 1));
+      a_row_off[i] = (size_t)min(row0 + row, N - 1) * K;
+    }
   }
   unsigned b_krow[G::LB];
   unsigned b_col[G::LB];
@@ -127,8 +134,9 @@ __global__ __launch_bounds__(G::THREADS) void mfma_f32_kernel(const float *__res
     char *base = smem + buf * G::STAGE_BYTES;
 #pragma unroll
     for (int i = 0; i < G::LA; ++i) {
-      const unsigned kk = min(k0 + a_kchunk[i] * 4, K - 4);
-      const float *src = A + a_row_off[i] + kk;
+      const float *src;
+      if (AT) src = A + (size_t)min(k0 + a_kchunk[i], K - 1) * N + a_row_off[i];
+      else src = A + a_row_off[i] + min(k0 + a_kchunk[i] * 4, K - 4);
       __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(base + (wave + G::NW * i) * 1024), 16, 0, 0);
     }
 #pragma unroll
@@ -142,7 +150,8 @@ __global__ __launch_bounds__(G::THREADS) void mfma_f32_kernel(const float *__res
   // ---- per-lane fragment addresses (bytes inside a stage) -------------------------------------
   // A: row = wm*TM*32 + mi*32 + lo; chunk = (2*kg + hi) ^ swz(row) = (2*kg) ^ (hi ^ swz(lo))
   const unsigned a_swz = hi ^ ((lo >> G::SWZ_SHIFT) & (CPR - 1));
-  const unsigned a_frag_base = (wm * TM * 32 + lo) * (BK * 4);
+  const unsigned a_frag_base = AT ? (4 * hi) * (G::BM * 4) + (wm * TM * 32 + TM * lo) * 4  // [k][row], TM rows per lane
+                                  : (wm * TM * 32 + lo) * (BK * 4);
   // B: k = kg*8 + p + 4*hi; col = wn*128 + 4*lo
   const unsigned b_frag_base = G::A_BYTES + (4 * hi) * (G::BN * 4) + (wn * 128 + 4 * lo) * 4;
 
@@ -162,9 +171,20 @@ __global__ __launch_bounds__(G::THREADS) void mfma_f32_kernel(const float *__res
   auto load_frags = [&](unsigned buf, int kg, f32x4 (&af)[TM], f32x4 (&bf)[4]) {
     const char *base = smem + buf * G::STAGE_BYTES;
     const unsigned achunk = ((unsigned)(2 * kg) ^ a_swz) * 16;
+    if (AT) {
+      // lane reads TM consecutive rows of one k-row: row block mi then holds rows TM*i + mi
+      using fvec = __attribute__((ext_vector_type(TM))) float;
 #pragma unroll
-    for (int mi = 0; mi < TM; ++mi)
-      af[mi] = *(const f32x4 *)(base + a_frag_base + mi * 32 * (BK * 4) + achunk);
+      for (int p = 0; p < 4; ++p) {
+        const fvec v = *(const fvec *)(base + a_frag_base + (kg * 8 + p) * (G::BM * 4));
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) af[mi][p] = v[mi];
+      }
+    } else {
+#pragma unroll
+      for (int mi = 0; mi < TM; ++mi)
+        af[mi] = *(const f32x4 *)(base + a_frag_base + mi * 32 * (BK * 4) + achunk);
+    }
 #pragma unroll
     for (int p = 0; p < 4; ++p)
       bf[p] = *(const f32x4 *)(base + b_frag_base + (kg * 8 + p) * (G::BN * 4));
@@ -187,7 +207,8 @@ __global__ __launch_bounds__(G::THREADS) void mfma_f32_kernel(const float *__res
     for (int mi = 0; mi < TM; ++mi) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const unsigned row = row0 + wm * TM * 32 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        const unsigned ri = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        const unsigned row = row0 + wm * TM * 32 + (AT ? TM * ri + mi : mi * 32 + ri);
         if (ccol < M && row < N) {
           f32x4 *dst = (f32x4 *)(C + (size_t)row * M + ccol);
           f32x4 v;
@@ -295,7 +316,8 @@ __global__ __launch_bounds__(G::THREADS) void mfma_f32_kernel(const float *__res
       for (int mi = 0; mi < TM; ++mi) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const unsigned row = row0 + wm * TM * 32 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          const unsigned ri = (r & 3) + 8 * (r >> 2) + 4 * hi;
+          const unsigned row = row0 + wm * TM * 32 + (AT ? TM * ri + mi : mi * 32 + ri);
           if (row < N) {
             f32x4 *dst = (f32x4 *)(C + (size_t)row * M + ccol);
             f32x4 v;
@@ -319,8 +341,19 @@ template <typename G>
 int launch_geo(hipStream_t s, const Problem &p) {
   const unsigned tiles_n = (p.n + G::BM - 1) / G::BM, tiles_m = (p.m + G::BN - 1) / G::BN;
   static unsigned long long configured = 0;
-  if (int e = ensure_dynamic_lds((const void *)mfma_f32_kernel<G>, G::LDS_BYTES, configured)) return e;
-  hipLaunchKernelGGL((mfma_f32_kernel<G>), dim3(tiles_n * tiles_m), dim3(G::THREADS), G::LDS_BYTES, s,
+  if (int e = ensure_dynamic_lds((const void *)mfma_f32_kernel<G, false>, G::LDS_BYTES, configured)) return e;
+  hipLaunchKernelGGL((mfma_f32_kernel<G, false>), dim3(tiles_n * tiles_m), dim3(G::THREADS), G::LDS_BYTES, s,
+                     (const float *)p.a, (const float *)p.b, (float *)p.c, p.n, p.k, p.m, tiles_n, tiles_m);
+  return (int)hipGetLastError();
+}
+
+// A stored K x N: only the default geometry is instantiated for it.
+template <typename G>
+int launch_geo_at(hipStream_t s, const Problem &p) {
+  const unsigned tiles_n = (p.n + G::BM - 1) / G::BM, tiles_m = (p.m + G::BN - 1) / G::BN;
+  static unsigned long long configured = 0;
+  if (int e = ensure_dynamic_lds((const void *)mfma_f32_kernel<G, true>, G::LDS_BYTES, configured)) return e;
+  hipLaunchKernelGGL((mfma_f32_kernel<G, true>), dim3(tiles_n * tiles_m), dim3(G::THREADS), G::LDS_BYTES, s,
                      (const float *)p.a, (const float *)p.b, (float *)p.c, p.n, p.k, p.m, tiles_n, tiles_m);
   return (int)hipGetLastError();
 }
@@ -379,11 +412,13 @@ void mfma_f32_geometry(int v, unsigned *bm, unsigned *bn, unsigned *bk, unsigned
 }
 
 bool mfma_f32_serves(const Problem &p) {
-  return !p.a_transposed && p.n >= 1 && p.m >= 4 && p.k >= 8 && p.m % 4 == 0 && p.k % 8 == 0;
+  if (!(p.n >= 1 && p.m >= 4 && p.k >= 8 && p.m % 4 == 0 && p.k % 8 == 0)) return false;
+  return !p.a_transposed || (p.n >= 4 && p.n % 4 == 0);  // K x N A is DMA'd in 16-B chunks along N
 }
 
 int launch_mfma_f32(hipStream_t s, const Problem &p, int variant) {
   if (!mfma_f32_serves(p)) return kErrNotSupported;
+  if (p.a_transposed) return launch_geo_at<V8>(s, p);
   switch (variant) {
     case 0: return launch_geo<V0>(s, p);
     case 1: return launch_geo<V1>(s, p);

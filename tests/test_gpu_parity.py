@@ -59,6 +59,24 @@ def test_f32_mfma_every_variant(variant, shape, monkeypatch):
     assert np.max(rel) < F32_TOL, (variant, np.unravel_index(np.argmax(rel), rel.shape), rel.max())
 
 
+@pytest.mark.parametrize("shape", [(516, 528, 528), (4, 16, 16), (300, 64, 272), (1024, 4112, 512), (260, 8, 4)],
+                         ids=lambda s: "x".join(map(str, s)))
+def test_f32_mfma_transposed_a_layout(shape):
+    """MM_TRANSPOSED_A: A handed over as K x N (kernel/Memory.cpp:205-261, include/Utility.h:31-35)."""
+    n, k, m = shape
+    a, b = _oracle.fill("float", n, k, m)
+    at = np.ascontiguousarray(a.T)
+    cfg = g.make_config("float", transposed_a=True)
+    assert g.kernel_name(cfg, n, k, m).startswith("mfma_f32")
+    c, _ = g.matmul_capi(at, b, transposed_a=True)
+    exact = a.astype(np.float64) @ b.astype(np.float64)
+    rel = np.abs(c - exact) / exact
+    assert rel.max() < F32_TOL, (np.unravel_index(np.argmax(rel), rel.shape), rel.max())
+    # and it is the same arithmetic as the row-major path: identical bits
+    c_rm, _ = g.matmul_capi(a, b)
+    assert np.array_equal(c, c_rm)
+
+
 def test_f32_mfma_transpose_detecting_inputs():
     # asymmetric operands: A = identity-like selector, B with distinct entries everywhere
     n, k, m = 192, 64, 384

@@ -134,3 +134,24 @@ def test_test_simulation_reference_ctest_shape_on_gpu():
     r = run(os.path.join(ROOT, "bin", "TestSimulation.exe"), 513, 528, 528)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "Running simulation..." in r.stdout and "Matrix-matrix multiplication successfully verified." in r.stdout
+
+
+# ---- static-size build: MM_DYNAMIC_SIZES=OFF (CMakeLists.txt:21-24, host/RunHardware.cpp:18-22,62-70) -----
+STATIC_EXE = os.path.join(ROOT, "bin", "RunHardware_static_float_528x512x560.exe")
+
+
+def test_static_size_build_usage():
+    r = run(STATIC_EXE, "hw", "on", "extra")
+    assert r.returncode == 1 and "Usage: ./RunHardware.exe <mode [hw/hw_emu]> [<verify [on/off]>]" in r.stderr
+    assert run(STATIC_EXE, "512").returncode == 1  # sizes are not arguments of a static build
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("args", [(), ("hw",), ("hw_emu", "on"), ("hw", "off")])
+def test_static_size_build_runs_on_gpu(args):
+    r = run(STATIC_EXE, *args)
+    assert r.returncode == 0, r.stdout + r.stderr
+    m = PERF_LINE.search(r.stdout)
+    assert m
+    if "off" not in args:
+        assert "Successfully verified." in r.stdout
