@@ -19,6 +19,8 @@
 //     XORed with (k&3)<<2 on the DMA source side, which spreads the 4 rows over the 4 quadrants
 //     of the 256-B bank row: each half-wave then reads 256 distinct bytes.
 // Edges: N arbitrary, K % 16 == 0, M % 8 == 0 (reference contract for half: K % 32, M % 32).
+#include <cstdlib>
+
 #include "mm_common.h"
 
 namespace mm {
@@ -31,9 +33,10 @@ typedef short s4 __attribute__((vector_size(8)));
 typedef const __attribute__((address_space(1))) void *gptr_t;
 typedef __attribute__((address_space(3))) void *lptr_t;
 
-struct GeoH {
-  static constexpr int WM = 4, WN = 2, NS = 2;
-  static constexpr int TM = 2, TN = 4;
+template <int WM_, int WN_, int TM_>
+struct GeoHT {
+  static constexpr int WM = WM_, WN = WN_, NS = 2;
+  static constexpr int TM = TM_, TN = 4;
   static constexpr int NW = WM * WN, THREADS = NW * 64;
   static constexpr int BM = WM * TM * 32, BN = WN * TN * 32, BK = 64;  // 256 x 256 x 64
   static constexpr int CPR = 8;                                        // 16-B chunks per A row
@@ -45,7 +48,10 @@ struct GeoH {
   static constexpr int KS = BK / 16;                                   // MFMA k-steps per slab
   static_assert(NA % NW == 0 && NB % NW == 0, "DMA split");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+  static_assert(BN == 256, "B swizzle / chunk math assumes 256-column slabs");
 };
+using GeoH = GeoHT<4, 2, 2>;   // 256 x 256, 8 wavefronts of 64 x 128 (2 per SIMD)
+using GeoH4 = GeoHT<2, 2, 4>;  // 256 x 256, 4 wavefronts of 128 x 128 (1 per SIMD, 256 accumulators)
 
 // LDS-DMA issued from inline asm.  hipcc waits vmcnt(0) before every ds_read_b64_tr_b16 that
 // follows a __builtin_amdgcn_global_load_lds (the transpose-read builtin carries no alias
@@ -73,11 +79,11 @@ __device__ __forceinline__ h8 join(s4 lo, s4 hi) {
   return u.h;
 }
 
-__global__ __launch_bounds__(GeoH::THREADS) void mfma_f16_kernel(const _Float16 *__restrict__ A,
+template <typename G>
+__global__ __launch_bounds__(G::THREADS) void mfma_f16_kernel(const _Float16 *__restrict__ A,
                                                                  const _Float16 *__restrict__ B,
                                                                  _Float16 *__restrict__ C, unsigned N, unsigned K,
                                                                  unsigned M, unsigned tiles_n, unsigned tiles_m) {
-  using G = GeoH;
   constexpr int TM = G::TM, TN = G::TN, BK = G::BK, NS = G::NS, CPR = G::CPR;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const unsigned lane = threadIdx.x & 63u;
@@ -206,18 +212,30 @@ __global__ __launch_bounds__(GeoH::THREADS) void mfma_f16_kernel(const _Float16 
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // trailing ring refills (clamped, unread)
 
-  // ---- epilogue: one rounding f32 -> binary16; lane = one column, 32 lanes = 64 contiguous B --
-#pragma unroll
-  for (int ni = 0; ni < TN; ++ni) {
-    const unsigned col = col0 + wn * 128 + ni * 32 + lo;
-    if (col >= M) continue;
+  // ---- epilogue: one rounding f32 -> binary16, then through this wave's slice of the (now free)
+  // LDS ring so that global stores are 16 B per lane and 256 contiguous bytes per row instead of
+  // one half per lane (the MFMA result layout gives a lane ONE column of 16 rows).
+  __builtin_amdgcn_s_barrier();  // every wave has finished reading the last slab
+  {
+    constexpr int ROWS = TM * 32;                       // rows of this wave's tile, 128 columns = 256 B each
+    char *slice = smem + wave * (ROWS * 256);
 #pragma unroll
     for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
-      for (int rr = 0; rr < 16; ++rr) {
-        const unsigned row = row0 + wm * TM * 32 + mi * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * hi;
-        if (row < N) C[(size_t)row * M + col] = (_Float16)acc[mi][ni][rr];
-      }
+      for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+          const unsigned row = mi * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * hi;
+          *(_Float16 *)(slice + row * 256 + (ni * 32 + lo) * 2) = (_Float16)acc[mi][ni][rr];
+        }
+    using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+#pragma unroll
+    for (int it = 0; it < ROWS * 16 / 64; ++it) {
+      const unsigned c = it * 64 + lane, row = c / 16, ch = c % 16;
+      const u32x4 v = *(const u32x4 *)(slice + row * 256 + ch * 16);
+      const unsigned grow = row0 + wm * ROWS + row, gcol = col0 + wn * 128 + ch * 8;
+      if (grow < N && gcol < M) *(u32x4 *)(C + (size_t)grow * M + gcol) = v;
+    }
   }
 }
 
@@ -227,15 +245,21 @@ bool mfma_f16_serves(const Problem &p) {
   return !p.a_transposed && p.n >= 1 && p.m >= 8 && p.k >= 16 && p.m % 8 == 0 && p.k % 16 == 0;
 }
 
-int launch_mfma_f16(hipStream_t s, const Problem &p) {
-  if (!mfma_f16_serves(p)) return kErrNotSupported;
-  using G = GeoH;
+template <typename G>
+static int launch_h(hipStream_t s, const Problem &p) {
   const unsigned tiles_n = (p.n + G::BM - 1) / G::BM, tiles_m = (p.m + G::BN - 1) / G::BN;
   static unsigned long long configured = 0;
-  if (int e = ensure_dynamic_lds((const void *)mfma_f16_kernel, G::LDS_BYTES, configured)) return e;
-  hipLaunchKernelGGL(mfma_f16_kernel, dim3(tiles_n * tiles_m), dim3(G::THREADS), G::LDS_BYTES, s,
+  if (int e = ensure_dynamic_lds((const void *)mfma_f16_kernel<G>, G::LDS_BYTES, configured)) return e;
+  hipLaunchKernelGGL((mfma_f16_kernel<G>), dim3(tiles_n * tiles_m), dim3(G::THREADS), G::LDS_BYTES, s,
                      (const _Float16 *)p.a, (const _Float16 *)p.b, (_Float16 *)p.c, p.n, p.k, p.m, tiles_n, tiles_m);
   return (int)hipGetLastError();
+}
+
+int launch_mfma_f16(hipStream_t s, const Problem &p) {
+  if (!mfma_f16_serves(p)) return kErrNotSupported;
+  const char *v = getenv("MM_F16_VARIANT");  // tuning hook
+  if (v && atoi(v) == 1) return launch_h<GeoH4>(s, p);
+  return launch_h<GeoH>(s, p);
 }
 
 }  // namespace mm

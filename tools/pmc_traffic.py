@@ -29,7 +29,7 @@ def run_pass(counter, size, workdir):
     env = dict(os.environ, TMPDIR="/tmp")
     cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "-d", d, "-o", "pmc", "--output-format", "csv", "--",
            sys.executable, os.path.join(ROOT, "tools", "sweep.py"), "f32", "--sizes", str(size), "--variants",
-           os.environ.get("MM_F32_VARIANT", "0"), "--reps", "3"]
+           os.environ.get("MM_F32_VARIANT", "8"), "--reps", "3"]
     r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True)
     if r.returncode != 0:
         sys.stderr.write(r.stdout[-2000:] + r.stderr[-2000:])
