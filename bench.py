@@ -98,11 +98,19 @@ def main():
                          f"--nproc-per-node {args.gpus} --master-addr 127.0.0.1 --master-port P bench.py --gpus {args.gpus} ...")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
+    # MM_BENCH_DEVICE_MOD / MM_BENCH_BACKEND exist only so that the N>1 control flow can be smoke-tested
+    # on a 1-GPU box (both ranks on device 0, gloo instead of RCCL); the driver never sets them.
+    local_rank %= int(os.environ.get("MM_BENCH_DEVICE_MOD", torch.cuda.device_count()))
+    backend = os.environ.get("MM_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=dev)  # control plane only: barrier + max(t)
+        # control plane only: barrier + max(t).  The data path has no collective.
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
 
     from gemm_hls_amd.partition import row_slab
     n_total = args.size * world
@@ -138,7 +146,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     launch_ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps))
@@ -168,7 +176,7 @@ def main():
                        "rows_per_gpu": rows},
             "roofline": {"bound": "mfma", "achieved": round(achieved_tf, 2), "peak": PEAK_TFLOPS_F32_MFMA,
                          "unit": "TFLOP/s", "frac": round(achieved_tf / PEAK_TFLOPS_F32_MFMA, 4),
-                         "traffic": hbm_traffic_per_launch(),
+                         "traffic": hbm_traffic_per_launch() if args.size == SIZE else None,
                          "algorithmic_flops_per_launch": 2.0 * rows * k * m,
                          "avg_launch_ms": round(1e3 * avg_launch_s, 4)},
         }

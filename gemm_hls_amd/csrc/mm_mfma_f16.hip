@@ -33,16 +33,20 @@ typedef short s4 __attribute__((vector_size(8)));
 typedef const __attribute__((address_space(1))) void *gptr_t;
 typedef __attribute__((address_space(3))) void *lptr_t;
 
-template <int WM_, int WN_, int TM_>
+template <int WM_, int WN_, int TM_, int BK_ = 64, int NS_ = 2>
 struct GeoHT {
-  static constexpr int WM = WM_, WN = WN_, NS = 2;
+  static constexpr int WM = WM_, WN = WN_, NS = NS_;
   static constexpr int TM = TM_, TN = 4;
   static constexpr int NW = WM * WN, THREADS = NW * 64;
-  static constexpr int BM = WM * TM * 32, BN = WN * TN * 32, BK = 64;  // 256 x 256 x 64
-  static constexpr int CPR = 8;                                        // 16-B chunks per A row
+  static constexpr int BM = WM * TM * 32, BN = WN * TN * 32, BK = BK_;  // 256 x 256 x BK
+  static constexpr int CPR = BK * 2 / 16;                              // 16-B chunks per A row
+  static constexpr int SWZ_SHIFT = (CPR == 4) ? 2 : 1;
+  static_assert(BK == 32 || BK == 64, "BK");
   static constexpr int BROW = BN * 2, BCH = BROW / 16;                 // B k-row bytes / chunks
   static constexpr int A_BYTES = BM * BK * 2, B_BYTES = BK * BROW;
-  static constexpr int STAGE_BYTES = A_BYTES + B_BYTES, LDS_BYTES = NS * STAGE_BYTES;
+  static constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
+  static constexpr int EPI_BYTES = NW * TM * 32 * 256;  // epilogue staging: a [TM*32][128] half slice per wave
+  static constexpr int LDS_BYTES = NS * STAGE_BYTES > EPI_BYTES ? NS * STAGE_BYTES : EPI_BYTES;
   static constexpr int NA = A_BYTES / 1024, NB = B_BYTES / 1024;
   static constexpr int LA = NA / NW, LB = NB / NW;
   static constexpr int KS = BK / 16;                                   // MFMA k-steps per slab
@@ -52,6 +56,8 @@ struct GeoHT {
 };
 using GeoH = GeoHT<4, 2, 2>;   // 256 x 256, 8 wavefronts of 64 x 128 (2 per SIMD)
 using GeoH4 = GeoHT<2, 2, 4>;  // 256 x 256, 4 wavefronts of 128 x 128 (1 per SIMD, 256 accumulators)
+using GeoH32x4 = GeoHT<4, 2, 2, 32, 4>;  // 32-deep slabs, 4-slab ring: 3 slabs (96 KiB) in flight
+using GeoH32x3 = GeoHT<4, 2, 2, 32, 3>;  // 32-deep slabs, 3-slab ring
 
 // LDS-DMA issued from inline asm.  hipcc waits vmcnt(0) before every ds_read_b64_tr_b16 that
 // follows a __builtin_amdgcn_global_load_lds (the transpose-read builtin carries no alias
@@ -105,7 +111,7 @@ __global__ __launch_bounds__(G::THREADS) void mfma_f16_kernel(const _Float16 *__
   for (int i = 0; i < G::LA; ++i) {
     const unsigned slot = (wave + G::NW * i) * 64 + lane;
     const unsigned row = slot / CPR, pc = slot % CPR;
-    a_kchunk[i] = pc ^ ((row >> 1) & (CPR - 1));
+    a_kchunk[i] = pc ^ ((row >> G::SWZ_SHIFT) & (CPR - 1));
     a_row_off[i] = (size_t)min(row0 + row, N - 1) * K;
   }
   unsigned b_krow[G::LB], b_col[G::LB];
@@ -134,7 +140,7 @@ __global__ __launch_bounds__(G::THREADS) void mfma_f16_kernel(const _Float16 *__
 
   // ---- fragment addresses ----------------------------------------------------------------------
   // A: row = wm*64 + mi*32 + lo, chunk = (2*ks + hi) ^ swz(lo) = (2*ks) ^ (hi ^ swz)
-  const unsigned a_swz = hi ^ ((lo >> 1) & (CPR - 1));
+  const unsigned a_swz = hi ^ ((lo >> G::SWZ_SHIFT) & (CPR - 1));
   const unsigned a_frag_base = (wm * TM * 32 + lo) * (BK * 2);
   // B (tr read): x = lane & 15, group column half gq = (lane >> 4) & 1, r = x >> 2 (k row in block)
   //   k = ks*16 + 8*hi + 4*h + r ; logical chunk = wn*16 + ni*4 + 2*gq + ((x&3)>>1) ; +8 B if x odd
@@ -259,6 +265,8 @@ int launch_mfma_f16(hipStream_t s, const Problem &p) {
   if (!mfma_f16_serves(p)) return kErrNotSupported;
   const char *v = getenv("MM_F16_VARIANT");  // tuning hook
   if (v && atoi(v) == 1) return launch_h<GeoH4>(s, p);
+  if (v && atoi(v) == 2) return launch_h<GeoH32x4>(s, p);
+  if (v && atoi(v) == 3) return launch_h<GeoH32x3>(s, p);
   return launch_h<GeoH>(s, p);
 }
 

@@ -14,6 +14,7 @@
 // Environment: MM_GPUS=<g> splits the rows of C over g devices (no collective; default 1).
 #include <chrono>
 #include <cstdlib>
+#include <iomanip>
 #include <iostream>
 #include <random>
 #include <stdexcept>
@@ -163,7 +164,20 @@ int main(int argc, char **argv) {
       }
     }
     const auto perf = 1e-9 * (2 * static_cast<float>(size_n) * size_k * size_m) / elapsed;
-    std::cout << "Kernel executed in " << elapsed << " seconds, corresponding to a performance of " << perf << " GOp/s.\n";
+    // Same line as the reference (host/RunHardware.cpp:178-180).  Default stream formatting turns
+    // 1.2e6 GOp/s into "1.2e+06", which the reference's own parser (scripts/build_manager.py:601,
+    // "([\\d\\.]+) seconds[^\\d]+([\\d\\.]+) GOp/s") cannot read, so large values print in fixed notation.
+    std::cout << "Kernel executed in " << elapsed << " seconds, corresponding to a performance of ";
+    if (perf >= 1e6) {
+      const auto flags = std::cout.flags();
+      const auto prec = std::cout.precision();
+      std::cout << std::fixed << std::setprecision(0) << perf;
+      std::cout.flags(flags);
+      std::cout.precision(prec);
+    } else {
+      std::cout << perf;
+    }
+    std::cout << " GOp/s.\n";
   } catch (std::runtime_error const &err) {
     std::cerr << "Execution failed with error: \"" << err.what() << "\"." << std::endl;
     return 1;
