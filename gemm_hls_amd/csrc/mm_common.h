@@ -7,6 +7,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/mm_gemm.h"
 
@@ -103,6 +104,17 @@ inline int ensure_dynamic_lds(const void *func, int bytes, unsigned long long &m
   if (e != hipSuccess) return (int)e;
   __atomic_fetch_or(&mask, bit, __ATOMIC_RELEASE);
   return 0;
+}
+
+// Tile rasterisation: after the XCD remap, workgroups are ordered in bands of `band_rows` tile-rows
+// (column-major inside a band), so the 32 workgroups an XCD runs at once cover
+// band_rows x (32/band_rows) tiles and share A row-panels / B column-panels in that XCD's L2.
+// 4 measured best on the fp32 kernel (fabric fetch 30 GB per 16384^3 launch vs 51 GB at 8 and
+// 100 GB at 16; profiles/r01_band_rows_sweep.txt).  MM_BAND_ROWS overrides it for experiments.
+inline unsigned band_rows() {
+  const char *e = getenv("MM_BAND_ROWS");
+  const int v = e ? atoi(e) : 0;
+  return v > 0 ? (unsigned)v : 4u;
 }
 
 // XCD-aware remap of a 1-D workgroup id: the dispatcher places workgroup b on XCD b % 8

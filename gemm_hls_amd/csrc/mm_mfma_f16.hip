@@ -89,7 +89,7 @@ template <typename G>
 __global__ __launch_bounds__(G::THREADS) void mfma_f16_kernel(const _Float16 *__restrict__ A,
                                                                  const _Float16 *__restrict__ B,
                                                                  _Float16 *__restrict__ C, unsigned N, unsigned K,
-                                                                 unsigned M, unsigned tiles_n, unsigned tiles_m) {
+                                                                 unsigned M, unsigned tiles_n, unsigned tiles_m, unsigned kBand) {
   constexpr int TM = G::TM, TN = G::TN, BK = G::BK, NS = G::NS, CPR = G::CPR;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const unsigned lane = threadIdx.x & 63u;
@@ -99,7 +99,6 @@ __global__ __launch_bounds__(G::THREADS) void mfma_f16_kernel(const _Float16 *__
 
   const unsigned nwg = tiles_n * tiles_m;
   const unsigned lin = xcd_remap(blockIdx.x, nwg);
-  constexpr unsigned kBand = 8;
   const unsigned band = lin / (kBand * tiles_m), within = lin % (kBand * tiles_m);
   const unsigned rows_in_band = min(kBand, tiles_n - band * kBand);
   const unsigned row0 = (band * kBand + within % rows_in_band) * G::BM, col0 = (within / rows_in_band) * G::BN;
@@ -257,7 +256,7 @@ static int launch_h(hipStream_t s, const Problem &p) {
   static unsigned long long configured = 0;
   if (int e = ensure_dynamic_lds((const void *)mfma_f16_kernel<G>, G::LDS_BYTES, configured)) return e;
   hipLaunchKernelGGL((mfma_f16_kernel<G>), dim3(tiles_n * tiles_m), dim3(G::THREADS), G::LDS_BYTES, s,
-                     (const _Float16 *)p.a, (const _Float16 *)p.b, (_Float16 *)p.c, p.n, p.k, p.m, tiles_n, tiles_m);
+                     (const _Float16 *)p.a, (const _Float16 *)p.b, (_Float16 *)p.c, p.n, p.k, p.m, tiles_n, tiles_m, band_rows());
   return (int)hipGetLastError();
 }
 

@@ -47,6 +47,8 @@
 // chunks clamped / predicated); K % 8 == 0 (a partial last slab is consumed in 8-deep groups;
 // the DMA of its unused part is clamped to valid addresses and never read).  Everything else is
 // served by the predicated kernels (mm_valu_tile / mm_ordered).
+#include <cstdlib>
+
 #include "mm_common.h"
 
 namespace mm {
@@ -84,7 +86,8 @@ __global__ __launch_bounds__(G::THREADS) void mfma_f32_kernel(const float *__res
                                                               const float *__restrict__ B,
                                                               float *__restrict__ C, unsigned N,
                                                               unsigned K, unsigned M,
-                                                              unsigned tiles_n, unsigned tiles_m) {
+                                                              unsigned tiles_n, unsigned tiles_m,
+                                                              unsigned kBand) {
   constexpr int TM = G::TM, TN = G::TN, BK = G::BK, NS = G::NS, CPR = G::CPR;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -96,7 +99,6 @@ __global__ __launch_bounds__(G::THREADS) void mfma_f32_kernel(const float *__res
   // ---- workgroup -> output tile: XCD-contiguous chunks, then bands of 8 tile-rows ----------
   const unsigned nwg = tiles_n * tiles_m;
   const unsigned lin = xcd_remap(blockIdx.x, nwg);
-  constexpr unsigned kBand = 8;
   const unsigned band = lin / (kBand * tiles_m), within = lin % (kBand * tiles_m);
   const unsigned rows_in_band = min(kBand, tiles_n - band * kBand);
   const unsigned tile_row = band * kBand + within % rows_in_band;
@@ -343,7 +345,7 @@ int launch_geo(hipStream_t s, const Problem &p) {
   static unsigned long long configured = 0;
   if (int e = ensure_dynamic_lds((const void *)mfma_f32_kernel<G, false>, G::LDS_BYTES, configured)) return e;
   hipLaunchKernelGGL((mfma_f32_kernel<G, false>), dim3(tiles_n * tiles_m), dim3(G::THREADS), G::LDS_BYTES, s,
-                     (const float *)p.a, (const float *)p.b, (float *)p.c, p.n, p.k, p.m, tiles_n, tiles_m);
+                     (const float *)p.a, (const float *)p.b, (float *)p.c, p.n, p.k, p.m, tiles_n, tiles_m, band_rows());
   return (int)hipGetLastError();
 }
 
@@ -354,7 +356,7 @@ int launch_geo_at(hipStream_t s, const Problem &p) {
   static unsigned long long configured = 0;
   if (int e = ensure_dynamic_lds((const void *)mfma_f32_kernel<G, true>, G::LDS_BYTES, configured)) return e;
   hipLaunchKernelGGL((mfma_f32_kernel<G, true>), dim3(tiles_n * tiles_m), dim3(G::THREADS), G::LDS_BYTES, s,
-                     (const float *)p.a, (const float *)p.b, (float *)p.c, p.n, p.k, p.m, tiles_n, tiles_m);
+                     (const float *)p.a, (const float *)p.b, (float *)p.c, p.n, p.k, p.m, tiles_n, tiles_m, band_rows());
   return (int)hipGetLastError();
 }
 

@@ -47,7 +47,7 @@ template <typename G>
 __global__ __launch_bounds__(G::THREADS) void mfma_f64_kernel(const double *__restrict__ A,
                                                               const double *__restrict__ B,
                                                               double *__restrict__ C, unsigned N, unsigned K,
-                                                              unsigned M, unsigned tiles_n, unsigned tiles_m) {
+                                                              unsigned M, unsigned tiles_n, unsigned tiles_m, unsigned kBand) {
   constexpr int TM = G::TM, TP = G::TP, BK = G::BK, NS = G::NS, CPR = G::CPR;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const unsigned lane = threadIdx.x & 63u;
@@ -57,7 +57,6 @@ __global__ __launch_bounds__(G::THREADS) void mfma_f64_kernel(const double *__re
 
   const unsigned nwg = tiles_n * tiles_m;
   const unsigned lin = xcd_remap(blockIdx.x, nwg);
-  constexpr unsigned kBand = 8;
   const unsigned band = lin / (kBand * tiles_m), within = lin % (kBand * tiles_m);
   const unsigned rows_in_band = min(kBand, tiles_n - band * kBand);
   const unsigned row0 = (band * kBand + within % rows_in_band) * G::BM, col0 = (within / rows_in_band) * G::BN;
@@ -198,7 +197,7 @@ int launch_mfma_f64(hipStream_t s, const Problem &p) {
   static unsigned long long configured = 0;
   if (int e = ensure_dynamic_lds((const void *)mfma_f64_kernel<G>, G::LDS_BYTES, configured)) return e;
   hipLaunchKernelGGL((mfma_f64_kernel<G>), dim3(tiles_n * tiles_m), dim3(G::THREADS), G::LDS_BYTES, s,
-                     (const double *)p.a, (const double *)p.b, (double *)p.c, p.n, p.k, p.m, tiles_n, tiles_m);
+                     (const double *)p.a, (const double *)p.b, (double *)p.c, p.n, p.k, p.m, tiles_n, tiles_m, band_rows());
   return (int)hipGetLastError();
 }
 
