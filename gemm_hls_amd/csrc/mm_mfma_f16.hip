@@ -85,7 +85,7 @@ __device__ __forceinline__ h8 join(s4 lo, s4 hi) {
   return u.h;
 }
 
-template <typename G>
+template <typename G, bool AT>
 __global__ __launch_bounds__(G::THREADS) void mfma_f16_kernel(const _Float16 *__restrict__ A,
                                                                  const _Float16 *__restrict__ B,
                                                                  _Float16 *__restrict__ C, unsigned N, unsigned K,
@@ -109,9 +109,15 @@ __global__ __launch_bounds__(G::THREADS) void mfma_f16_kernel(const _Float16 *__
 #pragma unroll
   for (int i = 0; i < G::LA; ++i) {
     const unsigned slot = (wave + G::NW * i) * 64 + lane;
-    const unsigned row = slot / CPR, pc = slot % CPR;
-    a_kchunk[i] = pc ^ ((row >> G::SWZ_SHIFT) & (CPR - 1));
-    a_row_off[i] = (size_t)min(row0 + row, N - 1) * K;
+    if (AT) {  // A stored K x N: the slab is [BK][BM] with the same quadrant swizzle as B's
+      const unsigned kr = slot / (G::BM / 8), pc = slot % (G::BM / 8);
+      a_kchunk[i] = kr;
+      a_row_off[i] = min(row0 + (pc ^ ((kr & 3u) << 2)) * 8, N - 8);
+    } else {
+      const unsigned row = slot / CPR, pc = slot % CPR;
+      a_kchunk[i] = pc ^ ((row >> G::SWZ_SHIFT) & (CPR - 1));
+      a_row_off[i] = (size_t)min(row0 + row, N - 1) * K;
+    }
   }
   unsigned b_krow[G::LB], b_col[G::LB];
 #pragma unroll
@@ -127,8 +133,9 @@ __global__ __launch_bounds__(G::THREADS) void mfma_f16_kernel(const _Float16 *__
     const unsigned base = lds0 + buf * G::STAGE_BYTES;
 #pragma unroll
     for (int i = 0; i < G::LA; ++i) {
-      const unsigned kk = min(k0 + a_kchunk[i] * 8, K - 8);
-      dma16(A + a_row_off[i] + kk, base + (wave + G::NW * i) * 1024);
+      const _Float16 *src = AT ? A + (size_t)min(k0 + a_kchunk[i], K - 1) * N + a_row_off[i]
+                               : A + a_row_off[i] + min(k0 + a_kchunk[i] * 8, K - 8);
+      dma16(src, base + (wave + G::NW * i) * 1024);
     }
 #pragma unroll
     for (int i = 0; i < G::LB; ++i) {
@@ -149,6 +156,11 @@ __global__ __launch_bounds__(G::THREADS) void mfma_f16_kernel(const _Float16 *__
   unsigned b_ni_off[TN];
 #pragma unroll
   for (int ni = 0; ni < TN; ++ni) b_ni_off[ni] = b_lane_base + ((unsigned)ni ^ r) * 64;
+  // K x N layout of A: same transpose-read gather as B, over the [k][BM] image (row bytes BM*2)
+  unsigned at_mi_off[TM];
+#pragma unroll
+  for (int mi = 0; mi < TM; ++mi)
+    at_mi_off[mi] = (8 * hi + r) * (G::BM * 2) + (((wm * TM * 4 + mi * 4) ^ (r << 2)) + 2 * gq + ((x & 3u) >> 1)) * 16 + (x & 1u) * 8;
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -159,8 +171,18 @@ __global__ __launch_bounds__(G::THREADS) void mfma_f16_kernel(const _Float16 *__
   auto load_frags = [&](unsigned buf, int ks, h8 (&af)[TM], h8 (&bf)[TN]) {
     const char *base = smem + buf * G::STAGE_BYTES;
     const unsigned achunk = ((unsigned)(2 * ks) ^ a_swz) * 16;
+    if (AT) {
 #pragma unroll
-    for (int mi = 0; mi < TM; ++mi) af[mi] = *(const h8 *)(base + a_frag_base + mi * 32 * (BK * 2) + achunk);
+      for (int mi = 0; mi < TM; ++mi) {
+        const char *p = base + at_mi_off[mi] + ks * 16 * (G::BM * 2);
+        const s4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s4 __attribute__((address_space(3))) *)(lptr_t)p);
+        const s4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s4 __attribute__((address_space(3))) *)(lptr_t)(p + 4 * G::BM * 2));
+        af[mi] = join(v0, v1);
+      }
+    } else {
+#pragma unroll
+      for (int mi = 0; mi < TM; ++mi) af[mi] = *(const h8 *)(base + a_frag_base + mi * 32 * (BK * 2) + achunk);
+    }
 #pragma unroll
     for (int ni = 0; ni < TN; ++ni) {
       const char *p = base + b_ni_off[ni] + ks * 16 * G::BROW;
@@ -247,21 +269,23 @@ __global__ __launch_bounds__(G::THREADS) void mfma_f16_kernel(const _Float16 *__
 }  // namespace
 
 bool mfma_f16_serves(const Problem &p) {
-  return !p.a_transposed && p.n >= 1 && p.m >= 8 && p.k >= 16 && p.m % 8 == 0 && p.k % 16 == 0;
+  if (!(p.n >= 1 && p.m >= 8 && p.k >= 16 && p.m % 8 == 0 && p.k % 16 == 0)) return false;
+  return !p.a_transposed || (p.n >= 8 && p.n % 8 == 0);
 }
 
-template <typename G>
+template <typename G, bool AT = false>
 static int launch_h(hipStream_t s, const Problem &p) {
   const unsigned tiles_n = (p.n + G::BM - 1) / G::BM, tiles_m = (p.m + G::BN - 1) / G::BN;
   static unsigned long long configured = 0;
-  if (int e = ensure_dynamic_lds((const void *)mfma_f16_kernel<G>, G::LDS_BYTES, configured)) return e;
-  hipLaunchKernelGGL((mfma_f16_kernel<G>), dim3(tiles_n * tiles_m), dim3(G::THREADS), G::LDS_BYTES, s,
+  if (int e = ensure_dynamic_lds((const void *)mfma_f16_kernel<G, AT>, G::LDS_BYTES, configured)) return e;
+  hipLaunchKernelGGL((mfma_f16_kernel<G, AT>), dim3(tiles_n * tiles_m), dim3(G::THREADS), G::LDS_BYTES, s,
                      (const _Float16 *)p.a, (const _Float16 *)p.b, (_Float16 *)p.c, p.n, p.k, p.m, tiles_n, tiles_m, band_rows());
   return (int)hipGetLastError();
 }
 
 int launch_mfma_f16(hipStream_t s, const Problem &p) {
   if (!mfma_f16_serves(p)) return kErrNotSupported;
+  if (p.a_transposed) return launch_h<GeoH, true>(s, p);
   const char *v = getenv("MM_F16_VARIANT");  // tuning hook
   if (v && atoi(v) == 1) return launch_h<GeoH4>(s, p);
   if (v && atoi(v) == 2) return launch_h<GeoH32x4>(s, p);

@@ -43,7 +43,7 @@ struct GeoD {
   static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 };
 
-template <typename G>
+template <typename G, bool AT>
 __global__ __launch_bounds__(G::THREADS) void mfma_f64_kernel(const double *__restrict__ A,
                                                               const double *__restrict__ B,
                                                               double *__restrict__ C, unsigned N, unsigned K,
@@ -66,9 +66,14 @@ __global__ __launch_bounds__(G::THREADS) void mfma_f64_kernel(const double *__re
 #pragma unroll
   for (int i = 0; i < G::LA; ++i) {
     const unsigned slot = (wave + G::NW * i) * 64 + lane;
-    const unsigned row = slot / CPR, pc = slot % CPR;
-    a_kchunk[i] = pc ^ ((row >> 1) & (CPR - 1));
-    a_row_off[i] = (size_t)min(row0 + row, N - 1) * K;
+    if (AT) {  // A stored K x N: slab is [BK][BM] like B's; a_kchunk = k-row, a_row_off = column offset
+      a_kchunk[i] = slot / (G::BM / 2);
+      a_row_off[i] = min(row0 + (slot % (G::BM / 2)) * 2, N - 2);
+    } else {
+      const unsigned row = slot / CPR, pc = slot % CPR;
+      a_kchunk[i] = pc ^ ((row >> 1) & (CPR - 1));
+      a_row_off[i] = (size_t)min(row0 + row, N - 1) * K;
+    }
   }
   unsigned b_krow[G::LB], b_col[G::LB];
 #pragma unroll
@@ -81,8 +86,9 @@ __global__ __launch_bounds__(G::THREADS) void mfma_f64_kernel(const double *__re
     char *base = smem + buf * G::STAGE_BYTES;
 #pragma unroll
     for (int i = 0; i < G::LA; ++i) {
-      const unsigned kk = min(k0 + a_kchunk[i] * 2, K - 2);
-      __builtin_amdgcn_global_load_lds((gptr_t)(A + a_row_off[i] + kk), (lptr_t)(base + (wave + G::NW * i) * 1024), 16, 0, 0);
+      const double *src = AT ? A + (size_t)min(k0 + a_kchunk[i], K - 1) * N + a_row_off[i]
+                             : A + a_row_off[i] + min(k0 + a_kchunk[i] * 2, K - 2);
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(base + (wave + G::NW * i) * 1024), 16, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < G::LB; ++i) {
@@ -94,7 +100,9 @@ __global__ __launch_bounds__(G::THREADS) void mfma_f64_kernel(const double *__re
 
   // A: row = wm*64 + mi*16 + lo; chunk = (4*kg + g4) ^ swz(lo)
   const unsigned a_swz = (lo >> 1) & (CPR - 1);
-  const unsigned a_frag_base = (wm * 64 + lo) * (BK * 8);
+  // K x N layout: image [k][row]; a lane reads 2 consecutive rows of k-row 2*g4 + p, so row
+  // tiles pair up: tile 2q+t holds rows q*32 + 2*i + t
+  const unsigned a_frag_base = AT ? (2 * g4) * (G::BM * 8) + (wm * 64 + 2 * lo) * 8 : (wm * 64 + lo) * (BK * 8);
   // B: k = kg*8 + 2*g4 + p; col = wn*64 + pair*32 + 2*lo
   const unsigned b_frag_base = G::A_BYTES + (2 * g4) * (G::BN * 8) + (wn * 64 + 2 * lo) * 8;
 
@@ -110,8 +118,19 @@ __global__ __launch_bounds__(G::THREADS) void mfma_f64_kernel(const double *__re
   auto load_frags = [&](unsigned buf, int kg, f64x2 (&af)[TM], f64x2 (&bf)[2][TP]) {
     const char *base = smem + buf * G::STAGE_BYTES;
     const unsigned achunk = (((unsigned)(4 * kg) + g4) ^ a_swz) * 16;
+    if (AT) {
 #pragma unroll
-    for (int mi = 0; mi < TM; ++mi) af[mi] = *(const f64x2 *)(base + a_frag_base + mi * 16 * (BK * 8) + achunk);
+      for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int q = 0; q < TM / 2; ++q) {
+          const f64x2 v = *(const f64x2 *)(base + a_frag_base + (kg * 8 + p) * (G::BM * 8) + q * 32 * 8);
+          af[2 * q][p] = v[0];
+          af[2 * q + 1][p] = v[1];
+        }
+    } else {
+#pragma unroll
+      for (int mi = 0; mi < TM; ++mi) af[mi] = *(const f64x2 *)(base + a_frag_base + mi * 16 * (BK * 8) + achunk);
+    }
 #pragma unroll
     for (int p = 0; p < 2; ++p)
 #pragma unroll
@@ -171,7 +190,8 @@ __global__ __launch_bounds__(G::THREADS) void mfma_f64_kernel(const double *__re
     for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const unsigned row = row0 + wm * 64 + mi * 16 + g4 + 4 * r;
+        const unsigned ri = g4 + 4 * r;
+        const unsigned row = row0 + wm * 64 + (AT ? (mi >> 1) * 32 + 2 * ri + (mi & 1) : mi * 16 + ri);
         if (row < N) {
           f64x2 v;
           v[0] = acc[mi][pr][0][r];
@@ -187,16 +207,23 @@ using D0 = GeoD<4, 2, 2>;  // 256 x 128 tile, 8 wavefronts (2 per SIMD), 96 KiB 
 }  // namespace
 
 bool mfma_f64_serves(const Problem &p) {
-  return !p.a_transposed && p.n >= 1 && p.m >= 2 && p.k >= 8 && p.m % 2 == 0 && p.k % 8 == 0;
+  if (!(p.n >= 1 && p.m >= 2 && p.k >= 8 && p.m % 2 == 0 && p.k % 8 == 0)) return false;
+  return !p.a_transposed || (p.n >= 2 && p.n % 2 == 0);
 }
 
 int launch_mfma_f64(hipStream_t s, const Problem &p) {
   if (!mfma_f64_serves(p)) return kErrNotSupported;
   using G = D0;
   const unsigned tiles_n = (p.n + G::BM - 1) / G::BM, tiles_m = (p.m + G::BN - 1) / G::BN;
-  static unsigned long long configured = 0;
-  if (int e = ensure_dynamic_lds((const void *)mfma_f64_kernel<G>, G::LDS_BYTES, configured)) return e;
-  hipLaunchKernelGGL((mfma_f64_kernel<G>), dim3(tiles_n * tiles_m), dim3(G::THREADS), G::LDS_BYTES, s,
+  static unsigned long long configured = 0, configured_at = 0;
+  if (p.a_transposed) {
+    if (int e = ensure_dynamic_lds((const void *)mfma_f64_kernel<G, true>, G::LDS_BYTES, configured_at)) return e;
+    hipLaunchKernelGGL((mfma_f64_kernel<G, true>), dim3(tiles_n * tiles_m), dim3(G::THREADS), G::LDS_BYTES, s,
+                       (const double *)p.a, (const double *)p.b, (double *)p.c, p.n, p.k, p.m, tiles_n, tiles_m, band_rows());
+    return (int)hipGetLastError();
+  }
+  if (int e = ensure_dynamic_lds((const void *)mfma_f64_kernel<G, false>, G::LDS_BYTES, configured)) return e;
+  hipLaunchKernelGGL((mfma_f64_kernel<G, false>), dim3(tiles_n * tiles_m), dim3(G::THREADS), G::LDS_BYTES, s,
                      (const double *)p.a, (const double *)p.b, (double *)p.c, p.n, p.k, p.m, tiles_n, tiles_m, band_rows());
   return (int)hipGetLastError();
 }

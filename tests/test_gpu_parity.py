@@ -121,6 +121,23 @@ def test_f16_mfma_wide_accumulate_contract(shape):
     assert rel.max() <= 2.0 ** -11 * 1.01      # half an ulp of binary16 relative to the exact value (+f32 noise)
 
 
+@pytest.mark.parametrize("dtype,shape", [("double", (516, 528, 528)), ("double", (2, 8, 2)), ("double", (300, 64, 272)),
+                                         ("half", (520, 528, 528)), ("half", (8, 16, 8)), ("half", (304, 64, 272))],
+                         ids=lambda v: str(v))
+def test_f64_f16_mfma_transposed_a_layout(dtype, shape):
+    """MM_TRANSPOSED_A for the fp64 / fp16 matrix-core paths: same bits as the row-major path."""
+    n, k, m = shape
+    a, b = _oracle.fill(dtype, n, k, m)
+    cfg = g.make_config(dtype, transposed_a=True)
+    assert g.kernel_name(cfg, n, k, m).startswith("mfma_")
+    c, _ = g.matmul_capi(np.ascontiguousarray(a.T), b, dtype, transposed_a=True)
+    c_rm, _ = g.matmul_capi(a, b, dtype)
+    assert np.array_equal(c.view(np.uint8), c_rm.view(np.uint8))
+    exact = a.astype(np.float64) @ b.astype(np.float64)
+    tol = 1e-12 if dtype == "double" else 2.0 ** -10
+    assert np.max(np.abs(c.astype(np.float64) - exact) / exact) <= tol
+
+
 def test_f16_overflow_behaviour_matches_ieee():
     # K large enough that sums pass 65504: binary16 result is +inf, like a correctly rounded result
     n, k, m = 33, 4096, 64
