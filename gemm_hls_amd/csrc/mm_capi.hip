@@ -86,7 +86,7 @@ int f32_variant() {
   return cached;
 }
 
-enum Family { FAM_ORDERED, FAM_VALU_TILE, FAM_MFMA_F32, FAM_MFMA_F64, FAM_MFMA_F16 };
+enum Family { FAM_ORDERED, FAM_VALU_TILE, FAM_MFMA_F32, FAM_MFMA_F64, FAM_MFMA_F16, FAM_MFMA_I8 };
 
 Family choose(const mm_config_t &cfg, const mm::Problem &p) {
   if (cfg.path == MM_PATH_ORDERED) return FAM_ORDERED;
@@ -94,6 +94,7 @@ Family choose(const mm_config_t &cfg, const mm::Problem &p) {
   if (mul_add && cfg.dtype == MM_DTYPE_F32 && mm::mfma_f32_serves(p)) return FAM_MFMA_F32;
   if (mul_add && cfg.dtype == MM_DTYPE_F64 && mm::mfma_f64_serves(p)) return FAM_MFMA_F64;
   if (mul_add && cfg.dtype == MM_DTYPE_F16 && mm::mfma_f16_serves(p)) return FAM_MFMA_F16;
+  if (mul_add && (cfg.dtype == MM_DTYPE_I8 || cfg.dtype == MM_DTYPE_U8) && mm::mfma_i8_serves(p)) return FAM_MFMA_I8;
   return FAM_VALU_TILE;
 }
 
@@ -104,6 +105,7 @@ int dispatch(hipStream_t s, const mm_config_t &cfg, const mm::Problem &p) {
     case FAM_MFMA_F32: e = mm::launch_mfma_f32(s, p, f32_variant()); break;
     case FAM_MFMA_F64: e = mm::launch_mfma_f64(s, p); break;
     case FAM_MFMA_F16: e = mm::launch_mfma_f16(s, p); break;
+    case FAM_MFMA_I8: e = mm::launch_mfma_i8(s, p); break;
     case FAM_VALU_TILE:
       e = mm::launch_valu_tile(s, cfg, p);
       if (e == mm::kErrNotSupported) e = mm::launch_ordered(s, cfg, p);  // still the GPU
@@ -330,6 +332,7 @@ const char *mm_kernel_name(const mm_config_t *cfg, unsigned n, unsigned k, unsig
     case FAM_MFMA_F32: return mm::mfma_f32_name(f32_variant());
     case FAM_MFMA_F64: return "mfma_f64";
     case FAM_MFMA_F16: return "mfma_f16";
+    case FAM_MFMA_I8: return "mfma_i8";
     case FAM_VALU_TILE: return "valu_tile";
     default: return "ordered";
   }
@@ -356,6 +359,10 @@ int mm_kernel_info(const mm_config_t *cfg, unsigned n, unsigned k, unsigned m, m
       r.tile_n = 256; r.tile_m = 256; r.tile_k = 64; r.wavefronts = 8;
       r.inst_n = 32; r.inst_m = 32; r.inst_k = 16; r.ops_per_clk_per_cu = 4096.0;
       r.measured_issue_efficiency = 0.60;   // profiles/r01_pmc_f16.json (and the clock drops to ~1.7 GHz)
+      break;
+    case FAM_MFMA_I8:
+      r.tile_n = 256; r.tile_m = 256; r.tile_k = 128; r.wavefronts = 8;
+      r.inst_n = 32; r.inst_m = 32; r.inst_k = 32; r.ops_per_clk_per_cu = 8192.0;
       break;
     case FAM_VALU_TILE: {
       r.tile_n = 128; r.tile_m = 128; r.tile_k = 16; r.wavefronts = 4;

@@ -82,9 +82,11 @@ int launch_valu_tile(hipStream_t s, const mm_config_t &cfg, const Problem &p);
 int launch_mfma_f32(hipStream_t s, const Problem &p, int variant);
 int launch_mfma_f64(hipStream_t s, const Problem &p);
 int launch_mfma_f16(hipStream_t s, const Problem &p);
+int launch_mfma_i8(hipStream_t s, const Problem &p);
 bool mfma_f32_serves(const Problem &p);
 bool mfma_f64_serves(const Problem &p);
 bool mfma_f16_serves(const Problem &p);
+bool mfma_i8_serves(const Problem &p);
 const char *mfma_f32_name(int variant);
 void mfma_f32_geometry(int variant, unsigned *bm, unsigned *bn, unsigned *bk, unsigned *waves);
 int mfma_f32_num_variants();

@@ -372,10 +372,12 @@ using V7 = Geo<1, 4, 2, 32, 2, true, 16>;    // 128x256, 8 waves, 32x128 per wav
 using V8 = Geo<2, 4, 2, 16, 2, false, 1, 256>;  // V3 + flush into C every 4096 k
 using V9 = Geo<2, 4, 2, 16, 2, false, 1, 128>;  // V3 + flush into C every 2048 k
 using V10 = Geo<2, 4, 2, 32, 2, false, 1, 128>; // 256x256x32, 8 waves (144 KiB LDS), flush every 4096 k
+using V11 = Geo<2, 4, 2, 16, 3, false, 1, 256>; // V8 with a 3-slab ring (96 KiB)
+using V12 = Geo<2, 4, 2, 16, 4, false, 1, 256>; // V8 with a 4-slab ring (128 KiB)
 
 }  // namespace
 
-int mfma_f32_num_variants() { return 11; }
+int mfma_f32_num_variants() { return 13; }
 
 const char *mfma_f32_name(int v) {
   switch (v) {
@@ -390,6 +392,8 @@ const char *mfma_f32_name(int v) {
     case 8: return "mfma_f32_256x256x16_w8_flush4096";
     case 9: return "mfma_f32_256x256x16_w8_flush2048";
     case 10: return "mfma_f32_256x256x32_w8_flush4096";
+    case 11: return "mfma_f32_256x256x16_w8_flush4096_ns3";
+    case 12: return "mfma_f32_256x256x16_w8_flush4096_ns4";
   }
   return "?";
 }
@@ -409,6 +413,8 @@ void mfma_f32_geometry(int v, unsigned *bm, unsigned *bn, unsigned *bk, unsigned
     case 7: return geo_of<V7>(bm, bn, bk, waves);
     case 9: return geo_of<V9>(bm, bn, bk, waves);
     case 10: return geo_of<V10>(bm, bn, bk, waves);
+    case 11: return geo_of<V11>(bm, bn, bk, waves);
+    case 12: return geo_of<V12>(bm, bn, bk, waves);
     default: return geo_of<V8>(bm, bn, bk, waves);
   }
 }
@@ -433,6 +439,8 @@ int launch_mfma_f32(hipStream_t s, const Problem &p, int variant) {
     case 8: return launch_geo<V8>(s, p);
     case 9: return launch_geo<V9>(s, p);
     case 10: return launch_geo<V10>(s, p);
+    case 11: return launch_geo<V11>(s, p);
+    case 12: return launch_geo<V12>(s, p);
   }
   return kErrNotSupported;
 }

@@ -1,0 +1,232 @@
+// int8_t / uint8_t (Multiply, Add) fast path for gfx950 on v_mfma_i32_32x32x32_i8.
+//
+// Why the signed-int8 matrix core serves BOTH element types exactly: the reference's semiring on
+// an 8-bit Data_t wraps every product and every sum to 8 bits (hlslib::op::Multiply/Add return
+// Data_t), i.e. the result is sum_k a*b taken mod 2^8.  uint8 and int8 bit patterns are congruent
+// mod 2^8, products and sums of congruent numbers stay congruent, and the i32 accumulator wraps mod
+// 2^32 (a multiple of 2^8), so (int8)(i32 accumulator) is bit-identical to Naive
+// (include/Utility.h:18-42) for int8_t and for uint8_t (the type the reference special-cases at
+// CMakeLists.txt:46-47).  Checked against the oracle in tests/test_gpu_parity.py.
+//
+// Organisation as mm_mfma_f16.hip: 256 x 256 x 128(bytes) slabs, 8 wavefronts of 64 x 128, A operand
+// by one ds_read_b128 (16 consecutive k of a row, rows swizzled with (row>>1)&7), B operand (16
+// consecutive k of ONE column of the row-major B) by two ds_read_b64_tr_b8: lane i of a 16-lane
+// group receives column i of the [8 k][16 col] block whose rows the group's lanes point at,
+// out[i][j] = in[2j + (i>>3)][i&7] (profiles/r01_probe_ds_read_b64_tr_b8_and_mfma_i8.txt).  A B
+// k-row is 256 B = one bank row, so the 16-B chunk index is XORed with (k&7)<<1 on the DMA source
+// side: the 8 rows of a block then sit in 8 different chunk pairs and a half-wave reads 256
+// distinct bytes.  Operand layout of the MFMA (same probe): lane l, byte b <-> k = 16*(l>>5) + b.
+// Edges: N arbitrary, K % 32 == 0, M % 16 == 0 (reference contract for 1-byte types: K % 64,
+// M % 64); other shapes and a K x N A go to the predicated kernels.
+#include <cstdlib>
+
+#include "mm_common.h"
+
+namespace mm {
+namespace {
+
+using i32x4 = __attribute__((ext_vector_type(4))) int;
+using i32x16 = __attribute__((ext_vector_type(16))) int;
+typedef int v2i __attribute__((vector_size(8)));
+typedef __attribute__((address_space(3))) void *lptr_t;
+
+struct GeoI8 {
+  static constexpr int WM = 4, WN = 2, NS = 2, TM = 2, TN = 4;
+  static constexpr int NW = WM * WN, THREADS = NW * 64;
+  static constexpr int BM = 256, BN = 256, BK = 128;           // BK in elements == bytes
+  static constexpr int CPR = 8;                                // 16-B chunks per A row
+  static constexpr int BROW = BN, BCH = BROW / 16;             // B k-row bytes / chunks
+  static constexpr int A_BYTES = BM * BK, B_BYTES = BK * BROW;
+  static constexpr int STAGE_BYTES = A_BYTES + B_BYTES, LDS_BYTES = NS * STAGE_BYTES;
+  static constexpr int NA = A_BYTES / 1024, NB = B_BYTES / 1024;
+  static constexpr int LA = NA / NW, LB = NB / NW;
+  static constexpr int KS = BK / 32;                           // MFMA k-steps per slab
+};
+
+// asm LDS-DMA (see mm_mfma_f16.hip: transpose-read builtins make hipcc drain builtin DMAs)
+__device__ __forceinline__ void dma16(const void *gsrc, unsigned lds_byte_addr) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_byte_addr)
+      : "memory");
+}
+
+__device__ __forceinline__ i32x4 join(v2i lo, v2i hi) {
+  i32x4 r;
+  r[0] = lo[0]; r[1] = lo[1]; r[2] = hi[0]; r[3] = hi[1];
+  return r;
+}
+
+__global__ __launch_bounds__(GeoI8::THREADS) void mfma_i8_kernel(const signed char *__restrict__ A,
+                                                                 const signed char *__restrict__ B,
+                                                                 signed char *__restrict__ C, unsigned N, unsigned K,
+                                                                 unsigned M, unsigned tiles_n, unsigned tiles_m,
+                                                                 unsigned kBand) {
+  using G = GeoI8;
+  constexpr int TM = G::TM, TN = G::TN, BK = G::BK, NS = G::NS, CPR = G::CPR;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const unsigned lane = threadIdx.x & 63u;
+  const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const unsigned wm = wave / G::WN, wn = wave % G::WN;
+  const unsigned lo = lane & 31u, hi = lane >> 5;
+
+  const unsigned lin = xcd_remap(blockIdx.x, tiles_n * tiles_m);
+  const unsigned band = lin / (kBand * tiles_m), within = lin % (kBand * tiles_m);
+  const unsigned rows_in_band = min(kBand, tiles_n - band * kBand);
+  const unsigned row0 = (band * kBand + within % rows_in_band) * G::BM, col0 = (within / rows_in_band) * G::BN;
+
+  // ---- DMA sources ---------------------------------------------------------------------------
+  size_t a_row_off[G::LA];
+  unsigned a_kchunk[G::LA];
+#pragma unroll
+  for (int i = 0; i < G::LA; ++i) {
+    const unsigned slot = (wave + G::NW * i) * 64 + lane;
+    const unsigned row = slot / CPR, pc = slot % CPR;
+    a_kchunk[i] = pc ^ ((row >> 1) & (CPR - 1));
+    a_row_off[i] = (size_t)min(row0 + row, N - 1) * K;
+  }
+  unsigned b_krow[G::LB], b_col[G::LB];
+#pragma unroll
+  for (int i = 0; i < G::LB; ++i) {
+    const unsigned slot = (wave + G::NW * i) * 64 + lane;
+    const unsigned kr = slot / G::BCH, pc = slot % G::BCH;
+    b_krow[i] = kr;
+    b_col[i] = min(col0 + (pc ^ ((kr & 7u) << 1)) * 16, M - 16);  // k0 % 8 == 0, so (k0+kr)&7 == kr&7
+  }
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
+  auto stage = [&](unsigned buf, unsigned k0) {
+    const unsigned base = lds0 + buf * G::STAGE_BYTES;
+#pragma unroll
+    for (int i = 0; i < G::LA; ++i)
+      dma16(A + a_row_off[i] + min(k0 + a_kchunk[i] * 16, K - 16), base + (wave + G::NW * i) * 1024);
+#pragma unroll
+    for (int i = 0; i < G::LB; ++i)
+      dma16(B + (size_t)min(k0 + b_krow[i], K - 1) * M + b_col[i], base + G::A_BYTES + (wave + G::NW * i) * 1024);
+  };
+
+  // ---- fragment addresses ----------------------------------------------------------------------
+  const unsigned a_swz = hi ^ ((lo >> 1) & (CPR - 1));
+  const unsigned a_frag_base = (wm * TM * 32 + lo) * BK;
+  // B: source-lane role y = lane & 15 -> block row r = y >> 1, 8-byte half q = y & 1; gq = 16-col half
+  const unsigned y = lane & 15u, gq = (lane >> 4) & 1u, r = y >> 1, q = y & 1u;
+  const unsigned b_lane_base = G::A_BYTES + (16 * hi + r) * G::BROW + 8 * q;
+  unsigned b_ni_off[TN];
+#pragma unroll
+  for (int ni = 0; ni < TN; ++ni) b_ni_off[ni] = b_lane_base + ((((wn * 4 + ni) ^ r) * 2) + gq) * 16;
+
+  i32x16 acc[TM][TN];
+#pragma unroll
+  for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni) acc[mi][ni] = (i32x16)0;
+
+  auto load_frags = [&](unsigned buf, int ks, i32x4 (&af)[TM], i32x4 (&bf)[TN]) {
+    const char *base = smem + buf * G::STAGE_BYTES;
+    const unsigned achunk = ((unsigned)(2 * ks) ^ a_swz) * 16;
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) af[mi] = *(const i32x4 *)(base + a_frag_base + mi * 32 * BK + achunk);
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni) {
+      const char *p = base + b_ni_off[ni] + ks * 32 * G::BROW;
+      const v2i v0 = __builtin_amdgcn_ds_read_tr8_b64_v2i32((v2i __attribute__((address_space(3))) *)(lptr_t)p);
+      const v2i v1 = __builtin_amdgcn_ds_read_tr8_b64_v2i32((v2i __attribute__((address_space(3))) *)(lptr_t)(p + 8 * G::BROW));
+      bf[ni] = join(v0, v1);
+    }
+  };
+  auto mfma_step = [&](const i32x4 (&af)[TM], const i32x4 (&bf)[TN]) {
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < TN; ++ni)
+        acc[mi][ni] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+  };
+
+  const unsigned num_tiles = (K + BK - 1) / BK;
+  constexpr int L = G::LA + G::LB;
+#pragma unroll
+  for (int s = 0; s < NS; ++s) stage(s, s * BK);
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 1) * L) : "memory");
+  __builtin_amdgcn_s_barrier();
+
+  i32x4 af0[TM], bf0[TN], af1[TM], bf1[TN];
+  load_frags(0, 0, af0, bf0);
+  const unsigned steady = num_tiles - 1;
+  for (unsigned t = 0; t < steady; ++t) {
+    const unsigned buf = t % NS;
+#pragma unroll
+    for (int ks = 0; ks < G::KS; ++ks) {
+      i32x4(&afc)[TM] = (ks & 1) ? af1 : af0;
+      i32x4(&bfc)[TN] = (ks & 1) ? bf1 : bf0;
+      i32x4(&afn)[TM] = (ks & 1) ? af0 : af1;
+      i32x4(&bfn)[TN] = (ks & 1) ? bf0 : bf1;
+      if (ks + 1 < G::KS) {
+        load_frags(buf, ks + 1, afn, bfn);
+      } else {
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NS - 2) * L) : "memory");
+        __builtin_amdgcn_s_barrier();
+        stage(buf, (t + NS) * BK);
+        load_frags((t + 1) % NS, 0, afn, bfn);
+      }
+      mfma_step(afc, bfc);
+    }
+  }
+  {
+    const unsigned t = num_tiles - 1;
+    const int steps = (int)((K - t * BK) / 32);
+    for (int ks = 0; ks < steps; ++ks) {
+      load_frags(t % NS, ks, af0, bf0);
+      mfma_step(af0, bf0);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  // ---- epilogue: low 8 bits of the i32 sums, through the wave's LDS slice, 16-B global stores ----
+  __builtin_amdgcn_s_barrier();
+  {
+    constexpr int ROWS = TM * 32;
+    char *slice = smem + wave * (ROWS * 128);
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+          const unsigned row = mi * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * hi;
+          slice[row * 128 + ni * 32 + lo] = (char)acc[mi][ni][rr];
+        }
+    using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+#pragma unroll
+    for (int it = 0; it < ROWS * 8 / 64; ++it) {
+      const unsigned c = it * 64 + lane, row = c / 8, ch = c % 8;
+      const u32x4 v = *(const u32x4 *)(slice + row * 128 + ch * 16);
+      const unsigned grow = row0 + wm * ROWS + row, gcol = col0 + wn * 128 + ch * 16;
+      if (grow < N && gcol < M) *(u32x4 *)(C + (size_t)grow * M + gcol) = v;
+    }
+  }
+}
+
+}  // namespace
+
+bool mfma_i8_serves(const Problem &p) {
+  return !p.a_transposed && p.n >= 1 && p.m >= 16 && p.k >= 32 && p.m % 16 == 0 && p.k % 32 == 0;
+}
+
+int launch_mfma_i8(hipStream_t s, const Problem &p) {
+  if (!mfma_i8_serves(p)) return kErrNotSupported;
+  using G = GeoI8;
+  const unsigned tiles_n = (p.n + G::BM - 1) / G::BM, tiles_m = (p.m + G::BN - 1) / G::BN;
+  static unsigned long long configured = 0;
+  if (int e = ensure_dynamic_lds((const void *)mfma_i8_kernel, G::LDS_BYTES, configured)) return e;
+  hipLaunchKernelGGL(mfma_i8_kernel, dim3(tiles_n * tiles_m), dim3(G::THREADS), G::LDS_BYTES, s,
+                     (const signed char *)p.a, (const signed char *)p.b, (signed char *)p.c, p.n, p.k, p.m, tiles_n,
+                     tiles_m, band_rows());
+  return (int)hipGetLastError();
+}
+
+}  // namespace mm

@@ -46,7 +46,7 @@ def test_f32_mfma_default_vs_blas_and_exact(shape):
     assert np.max(np.abs(c - exact) / exact) < F32_TOL
 
 
-@pytest.mark.parametrize("variant", range(11))
+@pytest.mark.parametrize("variant", range(13))
 @pytest.mark.parametrize("shape", [(513, 528, 528), (300, 64, 272), (256, 8, 4), (37, 32, 48), (300, 8208, 272)],
                          ids=lambda s: "x".join(map(str, s)))
 def test_f32_mfma_every_variant(variant, shape, monkeypatch):
@@ -136,6 +136,24 @@ def test_f64_f16_mfma_transposed_a_layout(dtype, shape):
     exact = a.astype(np.float64) @ b.astype(np.float64)
     tol = 1e-12 if dtype == "double" else 2.0 ** -10
     assert np.max(np.abs(c.astype(np.float64) - exact) / exact) <= tol
+
+
+@pytest.mark.parametrize("dtype", ["int8_t", "uint8_t"])
+@pytest.mark.parametrize("shape", [(513, 544, 528), (1, 32, 16), (129, 96, 272), (300, 4128, 272), (257, 64, 1040)],
+                         ids=lambda s: "x".join(map(str, s)))
+def test_i8_mfma_is_bit_exact_mod_256(dtype, shape):
+    """8-bit (Multiply, Add) on the signed-int8 matrix core: u8 = s8 (mod 2^8), sums wrap mod 2^32,
+    so the low byte equals the reference's wrap-around Data_t arithmetic for both types."""
+    n, k, m = shape
+    a, b = _oracle.fill(dtype, n, k, m)
+    rng = np.random.default_rng(7)
+    # the seeded inputs are 1..10 only; also cover the full 8-bit range incl. the sign bit
+    a2 = rng.integers(0, 256, size=a.shape, dtype=np.uint8).view(a.dtype)
+    b2 = rng.integers(0, 256, size=b.shape, dtype=np.uint8).view(b.dtype)
+    assert g.kernel_name(g.make_config(dtype), n, k, m) == "mfma_i8"
+    for aa, bb in ((a, b), (a2, b2)):
+        c, _ = g.matmul_capi(aa, bb, dtype)
+        assert np.array_equal(c, _oracle.naive(dtype, "Multiply", "Add", aa, bb))
 
 
 def test_f16_overflow_behaviour_matches_ieee():

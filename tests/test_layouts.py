@@ -139,6 +139,39 @@ def test_f16_b_image_transpose_read_gather_and_banks():
             assert len(banks) == 64
 
 
+def test_i8_b_image_transpose_read_gather_and_banks():
+    BROW, BCH = 256, 16
+    lds = {}
+    for kr in range(128):
+        for pc in range(BCH):
+            lds[kr * BROW + pc * 16] = (kr, pc ^ ((kr & 7) << 1))
+
+    def element_at(byte_addr):
+        base = (byte_addr // 16) * 16
+        kr, lc = lds[base]
+        return kr, lc * 16 + (byte_addr - base)
+
+    for ks, h, ni, wn in itertools.product(range(4), range(2), range(4), range(2)):
+        def addr(l):
+            y, gq, hi = l & 15, (l >> 4) & 1, l >> 5
+            r, q = y >> 1, y & 1
+            return (16 * hi + r) * BROW + 8 * q + ((((wn * 4 + ni) ^ r) * 2) + gq) * 16 + ks * 32 * BROW + h * 8 * BROW
+        # hardware: out[i][j] = in[2j + (i>>3)][i&7] inside each 16-lane group
+        for l in range(64):
+            i, grp = l & 15, l & ~15
+            for j in range(8):
+                src_lane = grp + 2 * j + (i >> 3)
+                k, col = element_at(addr(src_lane) + (i & 7))
+                assert k == ks * 32 + 16 * (l >> 5) + 8 * h + j      # MFMA operand byte 8h+j <-> k = 16*(l>>5) + 8h + j
+                assert col == wn * 128 + ni * 32 + (l & 31)
+        for half in (range(0, 32), range(32, 64)):
+            banks = set()
+            for l in half:
+                for d in (0, 4):
+                    banks.add(((addr(l) + d) // 4) % 64)
+            assert len(banks) == 64
+
+
 def test_xcd_remap_is_a_bijection():
     def remap(bid, nwg):
         q, r = divmod(nwg, 8)
