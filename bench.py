@@ -32,7 +32,9 @@ def cpu_baseline(sample_n=1024):
     """The repo's own hlslib simulation path (reference kernel sources + test-only shim) on
     float sample_n^3; this is the checker's side of the house, never the product."""
     import _oracle
-    info = {"value": None, "unit": "GFLOP/s", "cores": os.cpu_count(), "kind": "reference",
+    # the reference's dataflow graph is 32 ProcessingElement threads + 7 data movers (kernel/Top.cpp:67-116)
+    info = {"value": None, "unit": "GFLOP/s", "cores": min(39, os.cpu_count() or 1), "host_cores": os.cpu_count(),
+            "kind": "reference",
             "sample": f"float {sample_n}x{sample_n}x{sample_n} (BASELINE config C1), one call of the reference's "
                       "MatrixMultiplicationKernel compiled from /root/reference/kernel/*.cpp against "
                       "oracle/hlslib_shim: 32 ProcessingElement threads + 7 data movers"}

@@ -1,0 +1,86 @@
+"""Randomised shape fuzz on the GPU: every fast family against an independent result, over shapes
+that straddle tile edges, partial k-slabs, flush boundaries (fp32 flushes its accumulators every
+4096 k) and the minimum sizes each family accepts.  Seeded, so failures reproduce."""
+import zlib
+
+import numpy as np
+import pytest
+
+import _oracle
+import gemm_hls_amd as g
+
+pytestmark = pytest.mark.gpu
+
+#            dtype      k-multiple m-multiple  tolerance (None = bit-exact vs oracle Naive)
+FAMILIES = {
+    "float": (8, 4, 1e-5),
+    "double": (8, 2, 1e-12),
+    "half": (16, 8, 2.0 ** -10),
+    "uint8_t": (32, 16, None),
+    "int8_t": (32, 16, None),
+}
+
+
+def _shapes(rng, kmul, mmul, count):
+    out = []
+    for i in range(count):
+        n = int(rng.choice([1, 2, 31, 32, 33, 63, 64, 65, 127, 128, 129, 255, 256, 257, 300, 511, 513, 700]))
+        m = int(rng.choice([1, 2, 3, 7, 8, 15, 16, 17, 31, 32, 33, 40, 64, 65])) * mmul
+        if i % 7 == 0:
+            k = int(rng.choice([4096, 4096 + kmul, 8192 - kmul, 8192 + 2 * kmul]))  # around flush boundaries
+            n, m = min(n, 300), min(m, 40 * mmul)
+        else:
+            k = int(rng.integers(1, 40)) * kmul
+        out.append((n, k, m))
+    return out
+
+
+@pytest.mark.parametrize("dtype", list(FAMILIES))
+def test_fuzz_fast_family_shapes(dtype):
+    kmul, mmul, tol = FAMILIES[dtype]
+    rng = np.random.default_rng(zlib.crc32(dtype.encode()))
+    npdt = _oracle.NP_DTYPES[dtype]
+    for (n, k, m) in _shapes(rng, kmul, mmul, 40):
+        name = g.kernel_name(g.make_config(dtype), n, k, m)
+        assert name.startswith("mfma_"), (dtype, n, k, m, name)
+        if tol is None:
+            a = rng.integers(0, 256, size=(n, k), dtype=np.uint8).view(npdt)
+            b = rng.integers(0, 256, size=(k, m), dtype=np.uint8).view(npdt)
+            want = _oracle.naive(dtype, "Multiply", "Add", a, b)
+            c, _ = g.matmul_capi(a, b, dtype)
+            assert np.array_equal(c, want), (dtype, n, k, m)
+        else:
+            lo, hi = (0.5, 2.0) if dtype == "half" else (1.0, 10.0)  # keep half sums finite at K = 8192
+            a = rng.uniform(lo, hi, size=(n, k)).astype(npdt)
+            b = rng.uniform(lo, hi, size=(k, m)).astype(npdt)
+            exact = a.astype(np.float64) @ b.astype(np.float64)
+            c, _ = g.matmul_capi(a, b, dtype)
+            rel = np.abs(c.astype(np.float64) - exact) / exact
+            assert rel.max() <= tol, (dtype, n, k, m, float(rel.max()))
+
+
+@pytest.mark.parametrize("dtype,ops", [("float", ("Add", "Min")), ("int", ("Multiply", "Add")), ("double", ("Add", "Max")),
+                                        ("long", ("Min", "Max")), ("int16_t", ("Multiply", "Add"))])
+def test_fuzz_valu_tile_vs_ordered_and_oracle(dtype, ops):
+    rng = np.random.default_rng(11)
+    for (n, k, m) in _shapes(rng, 4, 4, 25):
+        k = min(k, 600)
+        a, b = _oracle.fill(dtype, n, k, m)
+        c_fast, _ = g.matmul_capi(a, b, dtype, *ops)
+        c_ord, _ = g.matmul_capi(a, b, dtype, *ops, path=g.PATH_ORDERED)
+        assert np.array_equal(c_fast.view(np.uint8), c_ord.view(np.uint8)), (dtype, ops, n, k, m)
+        assert np.array_equal(c_ord, _oracle.naive(dtype, ops[0], ops[1], a, b))
+
+
+def test_fuzz_unaligned_shapes_take_the_predicated_path_and_stay_exact():
+    rng = np.random.default_rng(5)
+    for _ in range(20):
+        n, k, m = (int(x) for x in rng.integers(1, 200, size=3))
+        for dtype, ops in (("float", ("Multiply", "Add")), ("int", ("Multiply", "Add")), ("float", ("Add", "Min"))):
+            a, b = _oracle.fill(dtype, n, k, m)
+            c, _ = g.matmul_capi(a, b, dtype, *ops)
+            want = _oracle.naive(dtype, ops[0], ops[1], a, b)
+            if dtype == "float" and ops == ("Multiply", "Add"):
+                assert _oracle.compare("float", c, want, 1e-5)[0] == 0, (n, k, m)
+            else:
+                assert np.array_equal(c, want), (dtype, ops, n, k, m)
