@@ -100,14 +100,20 @@ __global__ __launch_bounds__(GeoI8::THREADS) void mfma_i8_kernel(const signed ch
     b_col[i] = min(col0 + (pc ^ ((kr & 7u) << 1)) * 16, M - 16);  // k0 % 8 == 0, so (k0+kr)&7 == kr&7
   }
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
-  auto stage = [&](unsigned buf, unsigned k0) {
+  // part < 0: whole slab; part 0 / 1: even / odd DMA instructions (refill issued in two halves one
+  // k-step apart, see mm_mfma_f16.hip)
+  auto stage = [&](unsigned buf, unsigned k0, int part = -1) {
     const unsigned base = lds0 + buf * G::STAGE_BYTES;
 #pragma unroll
-    for (int i = 0; i < G::LA; ++i)
+    for (int i = 0; i < G::LA; ++i) {
+      if (part >= 0 && (i & 1) != part) continue;
       dma16(A + a_row_off[i] + min(k0 + a_kchunk[i] * 16, K - 16), base + (wave + G::NW * i) * 1024);
+    }
 #pragma unroll
-    for (int i = 0; i < G::LB; ++i)
+    for (int i = 0; i < G::LB; ++i) {
+      if (part >= 0 && (i & 1) != part) continue;
       dma16(B + (size_t)min(k0 + b_krow[i], K - 1) * M + b_col[i], base + G::A_BYTES + (wave + G::NW * i) * 1024);
+    }
   };
 
   // ---- fragment addresses ----------------------------------------------------------------------
@@ -166,11 +172,12 @@ __global__ __launch_bounds__(GeoI8::THREADS) void mfma_i8_kernel(const signed ch
       i32x4(&afn)[TM] = (ks & 1) ? af0 : af1;
       i32x4(&bfn)[TN] = (ks & 1) ? bf0 : bf1;
       if (ks + 1 < G::KS) {
+        if (ks == 0 && t > 0) stage((t + NS - 1) % NS, (t + NS - 1) * BK, 1);  // second half of the refill
         load_frags(buf, ks + 1, afn, bfn);
       } else {
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NS - 2) * L) : "memory");
         __builtin_amdgcn_s_barrier();
-        stage(buf, (t + NS) * BK);
+        stage(buf, (t + NS) * BK, 0);  // first half of the refill of the slot just freed
         load_frags((t + 1) % NS, 0, afn, bfn);
       }
       mfma_step(afc, bfc);
