@@ -62,6 +62,10 @@ def cpu_baseline(sample_n=1024):
     for _ in range(5):
         np.matmul(a, b)
     info["blas_sgemm_gflops_same_sample"] = round(5 * 2.0 * sample_n ** 3 / (time.perf_counter() - t0) / 1e9, 1)
+    # and the semantic spec, Naive (include/Utility.h:18-42), single-threaded
+    t0 = time.perf_counter()
+    _oracle.naive("float", "Multiply", "Add", a, b, threads=1)
+    info["naive_1thread_gflops_same_sample"] = round(2.0 * sample_n ** 3 / (time.perf_counter() - t0) / 1e9, 2)
     return info
 
 
