@@ -26,6 +26,16 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 PEAK_TFLOPS_F32_MFMA = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 SIZE = 16384
+# The default workload is BASELINE.json's metric (configs[1]).  The other single-GPU BASELINE
+# configs can be timed with --workload; they are parity-test cases, not the headline line.
+#            dtype     map         reduce  size   roof  peak (T op/s)  unit of the roof
+WORKLOADS = {
+    "float": ("float", "Multiply", "Add", 16384, "mfma", 157.3),
+    "half": ("half", "Multiply", "Add", 32768, "mfma", 2500.0),
+    "double": ("double", "Multiply", "Add", 16384, "mfma", 78.6),
+    "minplus": ("float", "Add", "Min", 8192, "valu", 65.0),   # measured VALU issue ceiling for 2 add + 1 min3
+    "uint8": ("uint8_t", "Multiply", "Add", 32768, "mfma", 5000.0),
+}
 
 
 def cpu_baseline(sample_n=1024):
@@ -87,13 +97,17 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--size", type=int, default=SIZE, help="N=K=M per GPU (default: BASELINE's 16384)")
+    ap.add_argument("--workload", choices=list(WORKLOADS), default="float")
+    ap.add_argument("--size", type=int, default=0, help="N=K=M per GPU (default: the workload's BASELINE size)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
     import torch
     import gemm_hls_amd as g
 
+    dtype, map_op, reduce_op, base_size, roof, peak = WORKLOADS[args.workload]
+    if not args.size:
+        args.size = base_size
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -123,16 +137,17 @@ def main():
     row0, rows = row_slab(n_total, world, rank)
     k = m = args.size
     # synthetic operands of the reference's distribution, generated in HBM
-    a = torch.empty((rows, k), dtype=torch.float32, device=dev)
-    b = torch.empty((k, m), dtype=torch.float32, device=dev)
-    c = torch.empty((rows, m), dtype=torch.float32, device=dev)
+    tdt = g.torch_dtype(dtype)
+    a = torch.empty((rows, k), dtype=tdt, device=dev)
+    b = torch.empty((k, m), dtype=tdt, device=dev)
+    c = torch.empty((rows, m), dtype=tdt, device=dev)
     L = g.lib()
-    g._check(L.mm_fill_device(local_rank, g.DTYPES["float"], a.data_ptr(), a.numel(), 1000 + rank))
-    g._check(L.mm_fill_device(local_rank, g.DTYPES["float"], b.data_ptr(), b.numel(), 7))
+    g._check(L.mm_fill_device(local_rank, g.DTYPES[dtype], a.data_ptr(), a.numel(), 1000 + rank))
+    g._check(L.mm_fill_device(local_rank, g.DTYPES[dtype], b.data_ptr(), b.numel(), 7))
     torch.cuda.set_device(local_rank)
 
     def step():
-        g.matmul(a, b, out=c)
+        g.matmul(a, b, dtype, map_op, reduce_op, out=c)
 
     def barrier():
         if world > 1:
@@ -162,8 +177,10 @@ def main():
         flops_job = 2.0 * n_total * k * m
         value = 1e-9 * flops_job * args.steps / elapsed
         achieved_tf = 2.0 * rows * k * m / avg_launch_s / 1e12
+        headline = args.workload == "float"
         out = {
-            "metric": "GFLOP/s, fp32 GEMM N=K=M=16384 per MI355X (tiled outer-product C=A.B), and % of fp32 MFMA peak",
+            "metric": ("GFLOP/s, fp32 GEMM N=K=M=16384 per MI355X (tiled outer-product C=A.B), and % of fp32 MFMA peak"
+                       if headline else f"GOp/s, {dtype} ({map_op},{reduce_op}) N=K=M={args.size} per MI355X"),
             "value": round(value, 1),
             "unit": "GFLOP/s",
             "n_gpus": world,
@@ -173,20 +190,21 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": {"float": "f32", "half": "f16 (f32 accumulate)", "double": "f64", "uint8_t": "u8 (i32 accumulate)"}[dtype],
             "data": "synthetic: uniform [1,10) (the reference generator's distribution), generated on device",
-            "pct_of_mfma_peak": round(100.0 * value / 1e3 / (PEAK_TFLOPS_F32_MFMA * world), 2),
-            "config": {"workload": f"float {n_total}x{k}x{m} (Multiply,Add), rows of C split over {world} GPU(s), "
-                                   "B replicated, no collective; BASELINE configs[1] per GPU",
-                       "kernel": g.kernel_name(g.make_config("float"), rows, k, m),
+            "pct_of_mfma_peak": round(100.0 * value / 1e3 / (peak * world), 2),
+            "config": {"workload": f"{dtype} {n_total}x{k}x{m} ({map_op},{reduce_op}), rows of C split over {world} GPU(s), "
+                                   "B replicated, no collective" + ("; BASELINE configs[1] per GPU" if headline else ""),
+                       "kernel": g.kernel_name(g.make_config(dtype, map_op, reduce_op), rows, k, m),
                        "rows_per_gpu": rows},
-            "roofline": {"bound": "mfma", "achieved": round(achieved_tf, 2), "peak": PEAK_TFLOPS_F32_MFMA,
-                         "unit": "TFLOP/s", "frac": round(achieved_tf / PEAK_TFLOPS_F32_MFMA, 4),
-                         "traffic": hbm_traffic_per_launch() if args.size == SIZE else None,
+            "roofline": {"bound": roof, "achieved": round(achieved_tf, 2), "peak": peak,
+                         "unit": "TFLOP/s" if roof == "mfma" and dtype != "uint8_t" else "TOp/s",
+                         "frac": round(achieved_tf / peak, 4),
+                         "traffic": hbm_traffic_per_launch() if (headline and args.size == SIZE) else None,
                          "algorithmic_flops_per_launch": 2.0 * rows * k * m,
                          "avg_launch_ms": round(1e3 * avg_launch_s, 4)},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and headline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if world > 1:
