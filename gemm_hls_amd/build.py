@@ -111,6 +111,15 @@ def build(verbose=True):
                               "-DMM_MAP_OP=Multiply", "-DMM_REDUCE_OP=Add", "-DMM_DYNAMIC_SIZES",
                               "-I" + os.path.join(ROOT, "include"), "-I" + host_dir, src, "-o", out,
                               "-L" + HERE, "-lmm_gemm_amd", rpath, "-ldl"])
+    # hardware probes cited by profiles/ (stand-alone HIP programs, not part of the product)
+    probe_dir = os.path.join(ROOT, "tools", "probes")
+    if os.path.isdir(probe_dir):
+        for f in sorted(os.listdir(probe_dir)):
+            if f.endswith(".hip"):
+                out = os.path.join(BIN, f[:-4])
+                if newer(out, [os.path.join(probe_dir, f)]):
+                    host_jobs.append([HIPCC, "--offload-arch=" + ARCH, "-O2", "-Wno-unused-result",
+                                      os.path.join(probe_dir, f), "-o", out])
     with concurrent.futures.ThreadPoolExecutor(max_workers=os.cpu_count() or 4) as ex:
         list(ex.map(run, host_jobs))
     if verbose and host_jobs:

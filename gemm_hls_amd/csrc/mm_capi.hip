@@ -76,14 +76,13 @@ bool valid_cfg(const mm_config_t *cfg) {
          (cfg->layout_a == MM_A_ROW_MAJOR || cfg->layout_a == MM_A_TRANSPOSED);
 }
 
+// fp32 geometry: 256x256x16, 8 wavefronts, accumulators flushed into C every 4096 k (146 TF at
+// 16384^3, max rel err 2.7e-6 over the full matrix: profiles/r01_f32_precision_full_matrix.txt).
+// MM_F32_VARIANT (re-read on every call) selects another one for sweeps: tools/sweep.py.
+constexpr int kDefaultF32Variant = 8;
 int f32_variant() {
-  static int cached = -2;
-  const char *e = getenv("MM_F32_VARIANT");  // tuning hook for bench sweeps; re-read each call
-  if (e && *e) return atoi(e);
-  // default: 256x256x16, 8 wavefronts, accumulators flushed into C every 4096 k
-  // (145 TF at 16384^3, max rel err 2.7e-6 over the full matrix: profiles/r01_f32_precision_full_matrix.txt)
-  if (cached == -2) cached = 8;
-  return cached;
+  const char *e = getenv("MM_F32_VARIANT");
+  return (e && *e) ? atoi(e) : kDefaultF32Variant;
 }
 
 enum Family { FAM_ORDERED, FAM_VALU_TILE, FAM_MFMA_F32, FAM_MFMA_F64, FAM_MFMA_F16, FAM_MFMA_I8 };
