@@ -79,10 +79,14 @@ bool valid_cfg(const mm_config_t *cfg) {
 // fp32 geometry: 256x256x16, 8 wavefronts, accumulators flushed into C every 4096 k (146 TF at
 // 16384^3, max rel err 2.7e-6 over the full matrix: profiles/r01_f32_precision_full_matrix.txt).
 // MM_F32_VARIANT (re-read on every call) selects another one for sweeps: tools/sweep.py.
-constexpr int kDefaultF32Variant = 8;
+// -1 = shape-adaptive choice among the flush-capable geometries (mm_mfma_f32.hip).
 int f32_variant() {
   const char *e = getenv("MM_F32_VARIANT");
-  return (e && *e) ? atoi(e) : kDefaultF32Variant;
+  return (e && *e) ? atoi(e) : -1;
+}
+int f32_variant_for(const mm::Problem &p) {
+  const int v = f32_variant();
+  return v >= 0 ? v : (p.a_transposed ? 8 : mm::mfma_f32_auto_variant(p));
 }
 
 enum Family { FAM_ORDERED, FAM_VALU_TILE, FAM_MFMA_F32, FAM_MFMA_F64, FAM_MFMA_F16, FAM_MFMA_I8 };
@@ -328,7 +332,7 @@ const char *mm_kernel_name(const mm_config_t *cfg, unsigned n, unsigned k, unsig
   if (!valid_cfg(cfg)) return "invalid";
   mm::Problem p{nullptr, nullptr, nullptr, n, k, m, cfg->layout_a == MM_A_TRANSPOSED};
   switch (choose(*cfg, p)) {
-    case FAM_MFMA_F32: return mm::mfma_f32_name(f32_variant());
+    case FAM_MFMA_F32: return mm::mfma_f32_name(f32_variant_for(p));
     case FAM_MFMA_F64: return "mfma_f64";
     case FAM_MFMA_F16: return "mfma_f16";
     case FAM_MFMA_I8: return "mfma_i8";
@@ -345,7 +349,7 @@ int mm_kernel_info(const mm_config_t *cfg, unsigned n, unsigned k, unsigned m, m
   r.max_clock_mhz = 2400.0;
   switch (choose(*cfg, p)) {
     case FAM_MFMA_F32:
-      mm::mfma_f32_geometry(f32_variant(), &r.tile_n, &r.tile_m, &r.tile_k, &r.wavefronts);
+      mm::mfma_f32_geometry(f32_variant_for(p), &r.tile_n, &r.tile_m, &r.tile_k, &r.wavefronts);
       r.inst_n = 32; r.inst_m = 32; r.inst_k = 2; r.ops_per_clk_per_cu = 256.0;   // 64 FLOP/clk/SIMD
       r.measured_issue_efficiency = 0.934;  // profiles/r01_pmc_f32_default.json
       break;

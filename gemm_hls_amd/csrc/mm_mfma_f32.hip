@@ -374,10 +374,12 @@ using V9 = Geo<2, 4, 2, 16, 2, false, 1, 128>;  // V3 + flush into C every 2048 
 using V10 = Geo<2, 4, 2, 32, 2, false, 1, 128>; // 256x256x32, 8 waves (144 KiB LDS), flush every 4096 k
 using V11 = Geo<2, 4, 2, 16, 3, false, 1, 256>; // V8 with a 3-slab ring (96 KiB)
 using V12 = Geo<2, 4, 2, 16, 4, false, 1, 256>; // V8 with a 4-slab ring (128 KiB)
+using V13 = Geo<2, 2, 2, 32, 2, false, 1, 128>; // 128x256x32, 4 waves, flush every 4096 k (mid-size shapes)
+using V14 = Geo<1, 4, 1, 32, 2, false, 1, 128>; // 128x128x32, 4 waves of 32x128, 64 KiB LDS: 2 workgroups per CU (small shapes)
 
 }  // namespace
 
-int mfma_f32_num_variants() { return 13; }
+int mfma_f32_num_variants() { return 15; }
 
 const char *mfma_f32_name(int v) {
   switch (v) {
@@ -394,6 +396,8 @@ const char *mfma_f32_name(int v) {
     case 10: return "mfma_f32_256x256x32_w8_flush4096";
     case 11: return "mfma_f32_256x256x16_w8_flush4096_ns3";
     case 12: return "mfma_f32_256x256x16_w8_flush4096_ns4";
+    case 13: return "mfma_f32_128x256x32_w4_flush4096";
+    case 14: return "mfma_f32_128x128x32_w4_flush4096";
   }
   return "?";
 }
@@ -415,8 +419,30 @@ void mfma_f32_geometry(int v, unsigned *bm, unsigned *bn, unsigned *bk, unsigned
     case 10: return geo_of<V10>(bm, bn, bk, waves);
     case 11: return geo_of<V11>(bm, bn, bk, waves);
     case 12: return geo_of<V12>(bm, bn, bk, waves);
+    case 13: return geo_of<V13>(bm, bn, bk, waves);
+    case 14: return geo_of<V14>(bm, bn, bk, waves);
     default: return geo_of<V8>(bm, bn, bk, waves);
   }
+}
+
+// Shape-adaptive geometry (variant < 0): the 256x256 tile is the fastest per CU, but a launch runs
+// in whole rounds of resident workgroups, so mid-size problems lose up to a round to quantisation
+// (6144^3: 576 tiles = 2.25 rounds of 256) and small ones leave CUs idle (2048^3: 64 tiles).  Pick
+// the candidate with the smallest estimated time = (workgroups the busiest CU runs) x tile area /
+// relative efficiency.
+int mfma_f32_auto_variant(const Problem &p) {
+  struct Cand { int variant; unsigned bm, bn, per_cu; double eff; };
+  static const Cand cands[] = {{8, 256, 256, 1, 1.00}, {13, 128, 256, 1, 0.95}, {14, 128, 128, 2, 0.88}};
+  double best = 0;
+  int pick = 8;
+  for (const Cand &c : cands) {
+    const unsigned long long tiles = (unsigned long long)((p.n + c.bm - 1) / c.bm) * ((p.m + c.bn - 1) / c.bn);
+    const unsigned long long slots = 256ull * c.per_cu, full = tiles / slots, rem = tiles % slots;
+    // full rounds keep per_cu workgroups on every CU; the last one only ceil(rem / 256)
+    const double t = ((double)full * c.per_cu + (double)((rem + 255) / 256)) * c.bm * c.bn / c.eff;  // ~ time
+    if (best == 0 || t < best * 0.999) { best = t; pick = c.variant; }
+  }
+  return pick;
 }
 
 bool mfma_f32_serves(const Problem &p) {
@@ -427,6 +453,7 @@ bool mfma_f32_serves(const Problem &p) {
 int launch_mfma_f32(hipStream_t s, const Problem &p, int variant) {
   if (!mfma_f32_serves(p)) return kErrNotSupported;
   if (p.a_transposed) return launch_geo_at<V8>(s, p);
+  if (variant < 0) variant = mfma_f32_auto_variant(p);
   switch (variant) {
     case 0: return launch_geo<V0>(s, p);
     case 1: return launch_geo<V1>(s, p);
@@ -441,6 +468,8 @@ int launch_mfma_f32(hipStream_t s, const Problem &p, int variant) {
     case 10: return launch_geo<V10>(s, p);
     case 11: return launch_geo<V11>(s, p);
     case 12: return launch_geo<V12>(s, p);
+    case 13: return launch_geo<V13>(s, p);
+    case 14: return launch_geo<V14>(s, p);
   }
   return kErrNotSupported;
 }

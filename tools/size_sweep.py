@@ -1,0 +1,19 @@
+#!/usr/bin/env python3
+"""fp32 (Multiply, Add) across problem sizes: shape-adaptive geometry (default) against the fixed
+256x256 tile.  Shows the round-quantisation effect the adaptive pick removes."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import sweep  # noqa: E402
+import gemm_hls_amd as g  # noqa: E402
+
+sizes = [512, 1024, 1536, 2048, 3072, 4096, 5120, 6144, 8192, 12288, 16384]
+print(f"{'size':>6}  {'adaptive kernel':38s} {'TF':>7}   {'fixed 256x256 TF':>16}")
+for s in sizes:
+    os.environ.pop("MM_F32_VARIANT", None)
+    name = g.kernel_name(g.make_config("float"), s, s, s)
+    med, _ = sweep.time_config("float", "Multiply", "Add", s, s, s, 5)
+    os.environ["MM_F32_VARIANT"] = "8"
+    med8, _ = sweep.time_config("float", "Multiply", "Add", s, s, s, 5)
+    print(f"{s:6d}  {name:38s} {2.0*s**3/med/1e12:7.1f}   {2.0*s**3/med8/1e12:16.1f}", flush=True)
