@@ -118,7 +118,7 @@ def build(verbose=True):
             if f.endswith(".hip"):
                 out = os.path.join(BIN, f[:-4])
                 if newer(out, [os.path.join(probe_dir, f)]):
-                    host_jobs.append([HIPCC, "--offload-arch=" + ARCH, "-O2", "-Wno-unused-result",
+                    host_jobs.append([HIPCC, "--offload-arch=" + ARCH, "-O2", "-w",
                                       os.path.join(probe_dir, f), "-o", out])
     with concurrent.futures.ThreadPoolExecutor(max_workers=os.cpu_count() or 4) as ex:
         list(ex.map(run, host_jobs))
