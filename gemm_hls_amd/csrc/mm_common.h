@@ -120,6 +120,24 @@ inline unsigned band_rows() {
   return v > 0 ? (unsigned)v : 4u;
 }
 
+// Shape-adaptive tile choice shared by the MFMA families.  A launch runs in rounds of resident
+// workgroups (256 CUs x per_cu), so a big tile loses up to a round to quantisation on mid-size
+// problems and leaves CUs idle on small ones.  Estimated time of a candidate ~ (workgroups the
+// busiest CU runs) x tile area / relative efficiency; the smallest wins.
+struct TileCandidate { int id; unsigned bm, bn, per_cu; double eff; };
+inline int pick_tile(const TileCandidate *cands, int count, unsigned n, unsigned m) {
+  double best = 0;
+  int pick = cands[0].id;
+  for (int i = 0; i < count; ++i) {
+    const TileCandidate &c = cands[i];
+    const unsigned long long tiles = (unsigned long long)((n + c.bm - 1) / c.bm) * ((m + c.bn - 1) / c.bn);
+    const unsigned long long slots = 256ull * c.per_cu, full = tiles / slots, rem = tiles % slots;
+    const double t = ((double)full * c.per_cu + (double)((rem + 255) / 256)) * c.bm * c.bn / c.eff;
+    if (best == 0 || t < best * 0.999) { best = t; pick = c.id; }
+  }
+  return pick;
+}
+
 // XCD-aware remap of a 1-D workgroup id: the dispatcher places workgroup b on XCD b % 8
 // (observed, used for speed only); give every XCD one contiguous chunk of the tile order so that
 // tiles sharing A row-panels / B column-panels meet in the same private L2.  Bijective for any

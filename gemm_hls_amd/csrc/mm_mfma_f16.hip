@@ -58,6 +58,7 @@ using GeoH = GeoHT<4, 2, 2>;   // 256 x 256, 8 wavefronts of 64 x 128 (2 per SIM
 using GeoH4 = GeoHT<2, 2, 4>;  // 256 x 256, 4 wavefronts of 128 x 128 (1 per SIMD, 256 accumulators)
 using GeoH32x4 = GeoHT<4, 2, 2, 32, 4>;  // 32-deep slabs, 4-slab ring: 3 slabs (96 KiB) in flight
 using GeoH32x3 = GeoHT<4, 2, 2, 32, 3>;  // 32-deep slabs, 3-slab ring
+using GeoHS = GeoHT<2, 2, 2>;            // 128 x 256, 4 wavefronts of 64 x 128: small / mid-size shapes
 
 // LDS-DMA issued from inline asm.  hipcc waits vmcnt(0) before every ds_read_b64_tr_b16 that
 // follows a __builtin_amdgcn_global_load_lds (the transpose-read builtin carries no alias
@@ -297,6 +298,11 @@ int launch_mfma_f16(hipStream_t s, const Problem &p) {
   if (v && atoi(v) == 1) return launch_h<GeoH4>(s, p);
   if (v && atoi(v) == 2) return launch_h<GeoH32x4>(s, p);
   if (v && atoi(v) == 3) return launch_h<GeoH32x3>(s, p);
+  if (v && atoi(v) == 4) return launch_h<GeoHS>(s, p);
+  if (!v) {
+    static const TileCandidate cands[] = {{0, 256, 256, 1, 1.00}, {4, 128, 256, 1, 0.80}};
+    if (pick_tile(cands, 2, p.n, p.m) == 4) return launch_h<GeoHS>(s, p);
+  }
   return launch_h<GeoH>(s, p);
 }
 

@@ -431,18 +431,8 @@ void mfma_f32_geometry(int v, unsigned *bm, unsigned *bn, unsigned *bk, unsigned
 // the candidate with the smallest estimated time = (workgroups the busiest CU runs) x tile area /
 // relative efficiency.
 int mfma_f32_auto_variant(const Problem &p) {
-  struct Cand { int variant; unsigned bm, bn, per_cu; double eff; };
-  static const Cand cands[] = {{8, 256, 256, 1, 1.00}, {13, 128, 256, 1, 0.95}, {14, 128, 128, 2, 0.88}};
-  double best = 0;
-  int pick = 8;
-  for (const Cand &c : cands) {
-    const unsigned long long tiles = (unsigned long long)((p.n + c.bm - 1) / c.bm) * ((p.m + c.bn - 1) / c.bn);
-    const unsigned long long slots = 256ull * c.per_cu, full = tiles / slots, rem = tiles % slots;
-    // full rounds keep per_cu workgroups on every CU; the last one only ceil(rem / 256)
-    const double t = ((double)full * c.per_cu + (double)((rem + 255) / 256)) * c.bm * c.bn / c.eff;  // ~ time
-    if (best == 0 || t < best * 0.999) { best = t; pick = c.variant; }
-  }
-  return pick;
+  static const TileCandidate cands[] = {{8, 256, 256, 1, 1.00}, {13, 128, 256, 1, 0.95}, {14, 128, 128, 2, 0.88}};
+  return pick_tile(cands, 3, p.n, p.m);
 }
 
 bool mfma_f32_serves(const Problem &p) {

@@ -16,6 +16,8 @@
 // Accumulation: one f64 fma chain per element (k order 0,2,4,6,1,3,5,7 inside each group).
 // Edges: N arbitrary, M % 2 == 0, K % 8 == 0 (the reference's own contract for double is
 // K % 8 == 0 and M % 8 == 0, host/RunHardware.cpp:50-61); other shapes -> predicated kernels.
+#include <cstdlib>
+
 #include "mm_common.h"
 
 namespace mm {
@@ -203,6 +205,7 @@ __global__ __launch_bounds__(G::THREADS) void mfma_f64_kernel(const double *__re
 }
 
 using D0 = GeoD<4, 2, 2>;  // 256 x 128 tile, 8 wavefronts (2 per SIMD), 96 KiB LDS
+using D1 = GeoD<2, 2, 2>;  // 128 x 128 tile, 4 wavefronts, 64 KiB LDS: two workgroups per CU (small / mid-size shapes)
 
 }  // namespace
 
@@ -211,9 +214,8 @@ bool mfma_f64_serves(const Problem &p) {
   return !p.a_transposed || (p.n >= 2 && p.n % 2 == 0);
 }
 
-int launch_mfma_f64(hipStream_t s, const Problem &p) {
-  if (!mfma_f64_serves(p)) return kErrNotSupported;
-  using G = D0;
+template <typename G>
+static int launch_d(hipStream_t s, const Problem &p) {
   const unsigned tiles_n = (p.n + G::BM - 1) / G::BM, tiles_m = (p.m + G::BN - 1) / G::BN;
   static unsigned long long configured = 0, configured_at = 0;
   if (p.a_transposed) {
@@ -226,6 +228,18 @@ int launch_mfma_f64(hipStream_t s, const Problem &p) {
   hipLaunchKernelGGL((mfma_f64_kernel<G, false>), dim3(tiles_n * tiles_m), dim3(G::THREADS), G::LDS_BYTES, s,
                      (const double *)p.a, (const double *)p.b, (double *)p.c, p.n, p.k, p.m, tiles_n, tiles_m, band_rows());
   return (int)hipGetLastError();
+}
+
+int mfma_f64_tile(const Problem &p) {  // 0: 256x128, 1: 128x128
+  const char *e = getenv("MM_F64_VARIANT");
+  if (e && *e) return atoi(e);
+  static const TileCandidate cands[] = {{0, 256, 128, 1, 1.00}, {1, 128, 128, 2, 0.74}};
+  return pick_tile(cands, 2, p.n, p.m);
+}
+
+int launch_mfma_f64(hipStream_t s, const Problem &p) {
+  if (!mfma_f64_serves(p)) return kErrNotSupported;
+  return mfma_f64_tile(p) == 1 ? launch_d<D1>(s, p) : launch_d<D0>(s, p);
 }
 
 }  // namespace mm
