@@ -354,12 +354,16 @@ int mm_kernel_info(const mm_config_t *cfg, unsigned n, unsigned k, unsigned m, m
       r.measured_issue_efficiency = 0.934;  // profiles/r01_pmc_f32_default.json
       break;
     case FAM_MFMA_F64:
-      r.tile_n = 256; r.tile_m = 128; r.tile_k = 16; r.wavefronts = 8;
+      if (mm::mfma_f64_tile(p) == 1) { r.tile_n = 128; r.tile_m = 128; r.wavefronts = 4; }
+      else { r.tile_n = 256; r.tile_m = 128; r.wavefronts = 8; }
+      r.tile_k = 16;
       r.inst_n = 16; r.inst_m = 16; r.inst_k = 4; r.ops_per_clk_per_cu = 128.0;
       r.measured_issue_efficiency = 0.92;
       break;
     case FAM_MFMA_F16:
-      r.tile_n = 256; r.tile_m = 256; r.tile_k = 64; r.wavefronts = 8;
+      if (mm::mfma_f16_tile(p) == 4) { r.tile_n = 128; r.tile_m = 256; r.wavefronts = 4; }
+      else { r.tile_n = 256; r.tile_m = 256; r.wavefronts = 8; }
+      r.tile_k = 64;
       r.inst_n = 32; r.inst_m = 32; r.inst_k = 16; r.ops_per_clk_per_cu = 4096.0;
       r.measured_issue_efficiency = 0.60;   // profiles/r01_pmc_f16.json (and the clock drops to ~1.7 GHz)
       break;

@@ -90,7 +90,9 @@ bool mfma_i8_serves(const Problem &p);
 const char *mfma_f32_name(int variant);
 void mfma_f32_geometry(int variant, unsigned *bm, unsigned *bn, unsigned *bk, unsigned *waves);
 int mfma_f32_num_variants();
-int mfma_f32_auto_variant(const Problem &p);  // shape-adaptive pick (variant < 0)
+int mfma_f32_auto_variant(const Problem &p);
+int mfma_f64_tile(const Problem &p);  // 0: 256x128, 1: 128x128
+int mfma_f16_tile(const Problem &p);  // 0: 256x256, 4: 128x256  // shape-adaptive pick (variant < 0)
 int launch_fill(hipStream_t s, mm_dtype_t dtype, void *ptr, size_t elements, unsigned long long seed);
 
 constexpr int kErrNotSupported = 801;  // hipErrorNotSupported

@@ -291,6 +291,11 @@ static int launch_h(hipStream_t s, const Problem &p) {
   return (int)hipGetLastError();
 }
 
+int mfma_f16_tile(const Problem &p) {  // 0: 256x256, 4: 128x256
+  static const TileCandidate cands[] = {{0, 256, 256, 1, 1.00}, {4, 128, 256, 1, 0.80}};
+  return p.a_transposed ? 0 : pick_tile(cands, 2, p.n, p.m);
+}
+
 int launch_mfma_f16(hipStream_t s, const Problem &p) {
   if (!mfma_f16_serves(p)) return kErrNotSupported;
   if (p.a_transposed) return launch_h<GeoH, true>(s, p);
@@ -299,10 +304,7 @@ int launch_mfma_f16(hipStream_t s, const Problem &p) {
   if (v && atoi(v) == 2) return launch_h<GeoH32x4>(s, p);
   if (v && atoi(v) == 3) return launch_h<GeoH32x3>(s, p);
   if (v && atoi(v) == 4) return launch_h<GeoHS>(s, p);
-  if (!v) {
-    static const TileCandidate cands[] = {{0, 256, 256, 1, 1.00}, {4, 128, 256, 1, 0.80}};
-    if (pick_tile(cands, 2, p.n, p.m) == 4) return launch_h<GeoHS>(s, p);
-  }
+  if (!v && mfma_f16_tile(p) == 4) return launch_h<GeoHS>(s, p);
   return launch_h<GeoH>(s, p);
 }
 
