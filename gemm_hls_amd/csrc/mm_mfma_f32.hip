@@ -376,10 +376,11 @@ using V11 = Geo<2, 4, 2, 16, 3, false, 1, 256>; // V8 with a 3-slab ring (96 KiB
 using V12 = Geo<2, 4, 2, 16, 4, false, 1, 256>; // V8 with a 4-slab ring (128 KiB)
 using V13 = Geo<2, 2, 2, 32, 2, false, 1, 128>; // 128x256x32, 4 waves, flush every 4096 k (mid-size shapes)
 using V14 = Geo<1, 4, 1, 32, 2, false, 1, 128>; // 128x128x32, 4 waves of 32x128, 64 KiB LDS: 2 workgroups per CU (small shapes)
+using V15 = Geo<2, 2, 2, 16, 2, false, 1, 256>; // 128x256x16, 4 waves, 48 KiB LDS: 2 independent workgroups per CU
 
 }  // namespace
 
-int mfma_f32_num_variants() { return 15; }
+int mfma_f32_num_variants() { return 16; }
 
 const char *mfma_f32_name(int v) {
   switch (v) {
@@ -398,6 +399,7 @@ const char *mfma_f32_name(int v) {
     case 12: return "mfma_f32_256x256x16_w8_flush4096_ns4";
     case 13: return "mfma_f32_128x256x32_w4_flush4096";
     case 14: return "mfma_f32_128x128x32_w4_flush4096";
+    case 15: return "mfma_f32_128x256x16_w4_flush4096_2percu";
   }
   return "?";
 }
@@ -421,6 +423,7 @@ void mfma_f32_geometry(int v, unsigned *bm, unsigned *bn, unsigned *bk, unsigned
     case 12: return geo_of<V12>(bm, bn, bk, waves);
     case 13: return geo_of<V13>(bm, bn, bk, waves);
     case 14: return geo_of<V14>(bm, bn, bk, waves);
+    case 15: return geo_of<V15>(bm, bn, bk, waves);
     default: return geo_of<V8>(bm, bn, bk, waves);
   }
 }
@@ -431,7 +434,7 @@ void mfma_f32_geometry(int v, unsigned *bm, unsigned *bn, unsigned *bk, unsigned
 // the candidate with the smallest estimated time = (workgroups the busiest CU runs) x tile area /
 // relative efficiency.
 int mfma_f32_auto_variant(const Problem &p) {
-  static const TileCandidate cands[] = {{8, 256, 256, 1, 1.00}, {13, 128, 256, 1, 0.95}, {14, 128, 128, 2, 0.88}};
+  static const TileCandidate cands[] = {{8, 256, 256, 1, 1.00}, {13, 128, 256, 1, 0.95}, {14, 128, 128, 2, 0.94}};
   return pick_tile(cands, 3, p.n, p.m);
 }
 
@@ -460,6 +463,7 @@ int launch_mfma_f32(hipStream_t s, const Problem &p, int variant) {
     case 12: return launch_geo<V12>(s, p);
     case 13: return launch_geo<V13>(s, p);
     case 14: return launch_geo<V14>(s, p);
+    case 15: return launch_geo<V15>(s, p);
   }
   return kErrNotSupported;
 }
