@@ -280,3 +280,29 @@ def test_f32_full_size_properties():
     assert torch.equal(cp, c[perm])
     # (4) determinism
     assert torch.equal(g.matmul(a, b), c)
+
+
+def test_f32_baseline_c5a_shape_on_one_gpu_large_offsets():
+    """BASELINE config 5a (65536 x 16384 x 16384) on ONE device: A and C are 4 GiB each, so byte
+    offsets exceed 32 bits.  Sampled rows (first, last, around the 4 GiB boundary) against fp64, and
+    the N-split property: a row slab computed alone equals the same rows of the full product."""
+    import torch
+    n, k, m = 65536, 16384, 16384
+    dev = torch.device("cuda:0")
+    L = g.lib()
+    a = torch.empty((n, k), dtype=torch.float32, device=dev)
+    b = torch.empty((k, m), dtype=torch.float32, device=dev)
+    assert L.mm_fill_device(0, 0, a.data_ptr(), a.numel(), 21) == 0
+    assert L.mm_fill_device(0, 0, b.data_ptr(), b.numel(), 22) == 0
+    c = g.matmul(a, b)
+    torch.cuda.synchronize()
+    rows = [0, 1, 32767, 32768, 49151, 65534, 65535]
+    b64 = b.double()
+    exact = (a[rows].double() @ b64).cpu().numpy()
+    got = c[rows].cpu().numpy()
+    assert np.max(np.abs(got - exact) / exact) < F32_TOL
+    # slab [3/8, 4/8) of an 8-way row split, computed on its own: identical bits
+    from gemm_hls_amd.partition import row_slab
+    row0, cnt = row_slab(n, 8, 3)
+    slab = g.matmul(a[row0:row0 + cnt].contiguous(), b)
+    assert torch.equal(slab, c[row0:row0 + cnt])
