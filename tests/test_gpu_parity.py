@@ -253,6 +253,22 @@ def test_reference_entry_point_symbol():
     assert _oracle.compare("float", c, a @ b, F32_TOL)[0] == 0
 
 
+def test_reference_entry_point_pipelined_in_row_slabs():
+    """Large host-pointer calls are pipelined in row slabs (copy-in / multiply / copy-out overlap);
+    the result must be the bits of the one-launch device path (ragged last slab included)."""
+    n, k, m = 4100, 4096, 4096
+    rng = np.random.default_rng(3)
+    a = rng.uniform(1, 10, size=(n, k)).astype(np.float32)
+    b = rng.uniform(1, 10, size=(k, m)).astype(np.float32)
+    c = np.zeros((n, m), np.float32)
+    g.lib().MatrixMultiplicationKernel(a.ctypes.data, b.ctypes.data, c.ctypes.data, n, k, m)
+    c_dev, _ = g.matmul_capi(a, b)
+    assert np.array_equal(c, c_dev)
+    rows = [0, 511, 512, 2047, 4095, 4099]
+    exact = a[rows].astype(np.float64) @ b.astype(np.float64)
+    assert np.max(np.abs(c[rows] - exact) / exact) < F32_TOL
+
+
 # ---- BASELINE.json full size: size-independent properties ------------------------------------
 def test_f32_full_size_properties():
     import torch
