@@ -99,7 +99,7 @@ Family choose(const mm_config_t &cfg, const mm::Problem &p) {
   if (mul_add && cfg.dtype == MM_DTYPE_F64 && mm::mfma_f64_serves(p)) return FAM_MFMA_F64;
   if (mul_add && cfg.dtype == MM_DTYPE_F16 && mm::mfma_f16_serves(p)) return FAM_MFMA_F16;
   if (mul_add && (cfg.dtype == MM_DTYPE_I8 || cfg.dtype == MM_DTYPE_U8) && mm::mfma_i8_serves(p)) return FAM_MFMA_I8;
-  return FAM_VALU_TILE;
+  return mm::valu_tile_serves(cfg, p) ? FAM_VALU_TILE : FAM_ORDERED;
 }
 
 int dispatch(hipStream_t s, const mm_config_t &cfg, const mm::Problem &p) {

@@ -79,6 +79,7 @@ struct Problem {
 // means "this family does not serve this (config, shape)".
 int launch_ordered(hipStream_t s, const mm_config_t &cfg, const Problem &p);
 int launch_valu_tile(hipStream_t s, const mm_config_t &cfg, const Problem &p);
+bool valu_tile_serves(const mm_config_t &cfg, const Problem &p);
 int launch_mfma_f32(hipStream_t s, const Problem &p, int variant);
 int launch_mfma_f64(hipStream_t s, const Problem &p);
 int launch_mfma_f16(hipStream_t s, const Problem &p);

@@ -51,6 +51,13 @@ def test_kernel_name_dispatch_table():
     assert g.kernel_name(g.make_config("float", path=g.PATH_ORDERED), 64, 64, 64) == "ordered"
     assert not g.kernel_name(g.make_config("float", "Add", "Min"), 64, 64, 64).startswith("mfma")
     assert not g.kernel_name(g.make_config("float"), 64, 62, 64).startswith("mfma")  # K % 8 != 0
+    assert g.kernel_name(g.make_config("float", "Add", "Min"), 64, 64, 64) == "valu_tile"
+    assert g.kernel_name(g.make_config("float", "Add", "Min"), 64, 63, 64) == "ordered"      # K % 4 != 0
+    assert g.kernel_name(g.make_config("int", "And", "Add"), 64, 64, 64) == "ordered"        # And map
+    assert g.kernel_name(g.make_config("uint8_t"), 512, 512, 512) == "mfma_i8"
+    assert g.kernel_name(g.make_config("double"), 512, 512, 512) == "mfma_f64"
+    assert g.kernel_name(g.make_config("half"), 512, 512, 512) == "mfma_f16"
+    assert g.kernel_name(g.make_config("float", transposed_a=True), 512, 512, 512).startswith("mfma_f32")
 
 
 @pytest.mark.skipif(_has_gpu(), reason="only meaningful without a GPU")
