@@ -17,7 +17,7 @@
 // side: the 8 rows of a block then sit in 8 different chunk pairs and a half-wave reads 256
 // distinct bytes.  Operand layout of the MFMA (same probe): lane l, byte b <-> k = 16*(l>>5) + b.
 // Edges: N arbitrary, K % 32 == 0, M % 16 == 0 (reference contract for 1-byte types: K % 64,
-// M % 64); other shapes and a K x N A go to the predicated kernels.
+// M % 64); a K x N A (N % 16 == 0) is gathered like B; other shapes go to the predicated kernels.
 #include <cstdlib>
 
 #include "mm_common.h"
@@ -63,6 +63,7 @@ __device__ __forceinline__ i32x4 join(v2i lo, v2i hi) {
   return r;
 }
 
+template <bool AT>
 __global__ __launch_bounds__(GeoI8::THREADS) void mfma_i8_kernel(const signed char *__restrict__ A,
                                                                  const signed char *__restrict__ B,
                                                                  signed char *__restrict__ C, unsigned N, unsigned K,
@@ -87,9 +88,15 @@ __global__ __launch_bounds__(GeoI8::THREADS) void mfma_i8_kernel(const signed ch
 #pragma unroll
   for (int i = 0; i < G::LA; ++i) {
     const unsigned slot = (wave + G::NW * i) * 64 + lane;
-    const unsigned row = slot / CPR, pc = slot % CPR;
-    a_kchunk[i] = pc ^ ((row >> 1) & (CPR - 1));
-    a_row_off[i] = (size_t)min(row0 + row, N - 1) * K;
+    if (AT) {  // A stored K x N: slab [BK][BM] bytes with the same chunk swizzle as B's
+      const unsigned kr = slot / (G::BM / 16), pc = slot % (G::BM / 16);
+      a_kchunk[i] = kr;
+      a_row_off[i] = min(row0 + (pc ^ ((kr & 7u) << 1)) * 16, N - 16);
+    } else {
+      const unsigned row = slot / CPR, pc = slot % CPR;
+      a_kchunk[i] = pc ^ ((row >> 1) & (CPR - 1));
+      a_row_off[i] = (size_t)min(row0 + row, N - 1) * K;
+    }
   }
   unsigned b_krow[G::LB], b_col[G::LB];
 #pragma unroll
@@ -107,7 +114,9 @@ __global__ __launch_bounds__(GeoI8::THREADS) void mfma_i8_kernel(const signed ch
 #pragma unroll
     for (int i = 0; i < G::LA; ++i) {
       if (part >= 0 && (i & 1) != part) continue;
-      dma16(A + a_row_off[i] + min(k0 + a_kchunk[i] * 16, K - 16), base + (wave + G::NW * i) * 1024);
+      dma16(AT ? A + (size_t)min(k0 + a_kchunk[i], K - 1) * N + a_row_off[i]
+               : A + a_row_off[i] + min(k0 + a_kchunk[i] * 16, K - 16),
+            base + (wave + G::NW * i) * 1024);
     }
 #pragma unroll
     for (int i = 0; i < G::LB; ++i) {
@@ -125,6 +134,11 @@ __global__ __launch_bounds__(GeoI8::THREADS) void mfma_i8_kernel(const signed ch
   unsigned b_ni_off[TN];
 #pragma unroll
   for (int ni = 0; ni < TN; ++ni) b_ni_off[ni] = b_lane_base + ((((wn * 4 + ni) ^ r) * 2) + gq) * 16;
+  // K x N layout of A: the same transpose-read gather over the [k][BM] image (256-byte k-rows)
+  unsigned at_mi_off[TM];
+#pragma unroll
+  for (int mi = 0; mi < TM; ++mi)
+    at_mi_off[mi] = (16 * hi + r) * G::BM + 8 * q + ((((wm * TM + mi) ^ r) * 2) + gq) * 16;
 
   i32x16 acc[TM][TN];
 #pragma unroll
@@ -135,8 +149,18 @@ __global__ __launch_bounds__(GeoI8::THREADS) void mfma_i8_kernel(const signed ch
   auto load_frags = [&](unsigned buf, int ks, i32x4 (&af)[TM], i32x4 (&bf)[TN]) {
     const char *base = smem + buf * G::STAGE_BYTES;
     const unsigned achunk = ((unsigned)(2 * ks) ^ a_swz) * 16;
+    if (AT) {
 #pragma unroll
-    for (int mi = 0; mi < TM; ++mi) af[mi] = *(const i32x4 *)(base + a_frag_base + mi * 32 * BK + achunk);
+      for (int mi = 0; mi < TM; ++mi) {
+        const char *p = base + at_mi_off[mi] + ks * 32 * G::BM;
+        const v2i v0 = __builtin_amdgcn_ds_read_tr8_b64_v2i32((v2i __attribute__((address_space(3))) *)(lptr_t)p);
+        const v2i v1 = __builtin_amdgcn_ds_read_tr8_b64_v2i32((v2i __attribute__((address_space(3))) *)(lptr_t)(p + 8 * G::BM));
+        af[mi] = join(v0, v1);
+      }
+    } else {
+#pragma unroll
+      for (int mi = 0; mi < TM; ++mi) af[mi] = *(const i32x4 *)(base + a_frag_base + mi * 32 * BK + achunk);
+    }
 #pragma unroll
     for (int ni = 0; ni < TN; ++ni) {
       const char *p = base + b_ni_off[ni] + ks * 32 * G::BROW;
@@ -221,16 +245,24 @@ __global__ __launch_bounds__(GeoI8::THREADS) void mfma_i8_kernel(const signed ch
 }  // namespace
 
 bool mfma_i8_serves(const Problem &p) {
-  return !p.a_transposed && p.n >= 1 && p.m >= 16 && p.k >= 32 && p.m % 16 == 0 && p.k % 32 == 0;
+  if (!(p.n >= 1 && p.m >= 16 && p.k >= 32 && p.m % 16 == 0 && p.k % 32 == 0)) return false;
+  return !p.a_transposed || (p.n >= 16 && p.n % 16 == 0);
 }
 
 int launch_mfma_i8(hipStream_t s, const Problem &p) {
   if (!mfma_i8_serves(p)) return kErrNotSupported;
   using G = GeoI8;
   const unsigned tiles_n = (p.n + G::BM - 1) / G::BM, tiles_m = (p.m + G::BN - 1) / G::BN;
-  static unsigned long long configured = 0;
-  if (int e = ensure_dynamic_lds((const void *)mfma_i8_kernel, G::LDS_BYTES, configured)) return e;
-  hipLaunchKernelGGL(mfma_i8_kernel, dim3(tiles_n * tiles_m), dim3(G::THREADS), G::LDS_BYTES, s,
+  static unsigned long long configured = 0, configured_at = 0;
+  if (p.a_transposed) {
+    if (int e = ensure_dynamic_lds((const void *)mfma_i8_kernel<true>, G::LDS_BYTES, configured_at)) return e;
+    hipLaunchKernelGGL(mfma_i8_kernel<true>, dim3(tiles_n * tiles_m), dim3(G::THREADS), G::LDS_BYTES, s,
+                       (const signed char *)p.a, (const signed char *)p.b, (signed char *)p.c, p.n, p.k, p.m, tiles_n,
+                       tiles_m, band_rows());
+    return (int)hipGetLastError();
+  }
+  if (int e = ensure_dynamic_lds((const void *)mfma_i8_kernel<false>, G::LDS_BYTES, configured)) return e;
+  hipLaunchKernelGGL(mfma_i8_kernel<false>, dim3(tiles_n * tiles_m), dim3(G::THREADS), G::LDS_BYTES, s,
                      (const signed char *)p.a, (const signed char *)p.b, (signed char *)p.c, p.n, p.k, p.m, tiles_n,
                      tiles_m, band_rows());
   return (int)hipGetLastError();

@@ -122,9 +122,10 @@ def test_f16_mfma_wide_accumulate_contract(shape):
 
 
 @pytest.mark.parametrize("dtype,shape", [("double", (516, 528, 528)), ("double", (2, 8, 2)), ("double", (300, 64, 272)),
-                                         ("half", (520, 528, 528)), ("half", (8, 16, 8)), ("half", (304, 64, 272))],
+                                         ("half", (520, 528, 528)), ("half", (8, 16, 8)), ("half", (304, 64, 272)),
+                                         ("uint8_t", (528, 544, 528)), ("int8_t", (16, 32, 16)), ("uint8_t", (304, 4128, 272))],
                          ids=lambda v: str(v))
-def test_f64_f16_mfma_transposed_a_layout(dtype, shape):
+def test_f64_f16_i8_mfma_transposed_a_layout(dtype, shape):
     """MM_TRANSPOSED_A for the fp64 / fp16 matrix-core paths: same bits as the row-major path."""
     n, k, m = shape
     a, b = _oracle.fill(dtype, n, k, m)
@@ -133,6 +134,9 @@ def test_f64_f16_mfma_transposed_a_layout(dtype, shape):
     c, _ = g.matmul_capi(np.ascontiguousarray(a.T), b, dtype, transposed_a=True)
     c_rm, _ = g.matmul_capi(a, b, dtype)
     assert np.array_equal(c.view(np.uint8), c_rm.view(np.uint8))
+    if dtype in ("uint8_t", "int8_t"):
+        assert np.array_equal(c, _oracle.naive(dtype, "Multiply", "Add", a, b))
+        return
     exact = a.astype(np.float64) @ b.astype(np.float64)
     tol = 1e-12 if dtype == "double" else 2.0 ** -10
     assert np.max(np.abs(c.astype(np.float64) - exact) / exact) <= tol
