@@ -248,6 +248,25 @@ def test_multi_device_row_split_matches_single():
     assert np.array_equal(c1, cm) and t > 0
 
 
+def test_multi_device_api_contract():
+    import torch
+    have = torch.cuda.device_count()
+    a, b = _oracle.fill("int", 130, 64, 96)
+    want = _oracle.naive("int", "Multiply", "Add", a, b)
+    for devices in range(1, have + 1):            # every device count that exists on this box
+        c, t = g.matmul_host(a, b, "int", devices=devices)
+        assert np.array_equal(c, want) and t > 0
+    with pytest.raises(g.MMError, match="device_count"):
+        g.matmul_host(a, b, "int", devices=have + 1)   # never silently uses fewer devices
+    at = np.ascontiguousarray(a.T)
+    with pytest.raises(g.MMError):
+        cfg = g.make_config("int", transposed_a=True)
+        import ctypes
+        c = np.empty((130, 96), np.int32)
+        g._check(g.lib().mm_gemm_multi_device(1, ctypes.byref(cfg), at.ctypes.data, b.ctypes.data, c.ctypes.data,
+                                               130, 64, 96, None))
+
+
 def test_reference_entry_point_symbol():
     """extern "C" MatrixMultiplicationKernel(a, b, c, N, K, M) with host pointers (TestSimulation.cpp:66)."""
     n, k, m = 65, 32, 48
