@@ -128,7 +128,17 @@ def main():
         import torch.distributed as dist
         # control plane only: barrier + max(t).  The data path has no collective.
         if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=dev)
+            try:
+                dist.init_process_group(backend="nccl", device_id=dev)
+                probe = torch.zeros(1, device=dev)
+                dist.all_reduce(probe)            # builds the RCCL communicator now, outside the timed region
+                torch.cuda.synchronize()
+            except Exception as exc:              # control plane only: a host-side barrier serves as well
+                sys.stderr.write(f"[bench] RCCL control plane unavailable ({exc!r}); using gloo for barrier/max\n")
+                if dist.is_initialized():
+                    dist.destroy_process_group()
+                backend = "gloo"
+                dist.init_process_group(backend="gloo")
         else:
             dist.init_process_group(backend=backend)
 
