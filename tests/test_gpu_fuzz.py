@@ -1,6 +1,7 @@
 """Randomised shape fuzz on the GPU: every fast family against an independent result, over shapes
 that straddle tile edges, partial k-slabs, flush boundaries (fp32 flushes its accumulators every
 4096 k) and the minimum sizes each family accepts.  Seeded, so failures reproduce."""
+import os
 import zlib
 
 import numpy as np
@@ -10,6 +11,7 @@ import _oracle
 import gemm_hls_amd as g
 
 pytestmark = pytest.mark.gpu
+SCALE = int(os.environ.get("MM_FUZZ_SCALE", "1"))  # MM_FUZZ_SCALE=10 for a long soak
 
 #            dtype      k-multiple m-multiple  tolerance (None = bit-exact vs oracle Naive)
 FAMILIES = {
@@ -40,7 +42,7 @@ def test_fuzz_fast_family_shapes(dtype):
     kmul, mmul, tol = FAMILIES[dtype]
     rng = np.random.default_rng(zlib.crc32(dtype.encode()))
     npdt = _oracle.NP_DTYPES[dtype]
-    for (n, k, m) in _shapes(rng, kmul, mmul, 40):
+    for (n, k, m) in _shapes(rng, kmul, mmul, 40 * SCALE):
         name = g.kernel_name(g.make_config(dtype), n, k, m)
         assert name.startswith("mfma_"), (dtype, n, k, m, name)
         if tol is None:
@@ -63,7 +65,7 @@ def test_fuzz_fast_family_shapes(dtype):
                                         ("long", ("Min", "Max")), ("int16_t", ("Multiply", "Add"))])
 def test_fuzz_valu_tile_vs_ordered_and_oracle(dtype, ops):
     rng = np.random.default_rng(11)
-    for (n, k, m) in _shapes(rng, 4, 4, 25):
+    for (n, k, m) in _shapes(rng, 4, 4, 25 * SCALE):
         k = min(k, 600)
         a, b = _oracle.fill(dtype, n, k, m)
         c_fast, _ = g.matmul_capi(a, b, dtype, *ops)
@@ -74,7 +76,7 @@ def test_fuzz_valu_tile_vs_ordered_and_oracle(dtype, ops):
 
 def test_fuzz_unaligned_shapes_take_the_predicated_path_and_stay_exact():
     rng = np.random.default_rng(5)
-    for _ in range(20):
+    for _ in range(20 * SCALE):
         n, k, m = (int(x) for x in rng.integers(1, 200, size=3))
         for dtype, ops in (("float", ("Multiply", "Add")), ("int", ("Multiply", "Add")), ("float", ("Add", "Min"))):
             a, b = _oracle.fill(dtype, n, k, m)
