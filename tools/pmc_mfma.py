@@ -18,8 +18,10 @@ PASSES = [
     ["SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES"],
     ["SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE"],
     ["TCC_HIT_sum", "TCC_MISS_sum"],
+    ["SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_VMEM", "SQ_INSTS_VALU", "SQ_INSTS_LDS"],
 ]
-KERNEL = {"f32": "mfma_f32_kernel", "f64": "mfma_f64_kernel", "f16": "mfma_f16_kernel", "minplus": "valu_tile_kernel"}
+KERNEL = {"f32": "mfma_f32_kernel", "f64": "mfma_f64_kernel", "f16": "mfma_f16_kernel", "minplus": "valu_tile_kernel",
+          "uint8": "mfma_i8_kernel"}
 
 
 def run_pass(counters, what, size, workdir, idx):

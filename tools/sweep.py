@@ -38,7 +38,7 @@ def time_config(dtype, mp, rd, n, k, m, reps, path=g.PATH_AUTO):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["f32", "f64", "f16", "minplus", "all"])
+    ap.add_argument("what", choices=["f32", "f64", "f16", "minplus", "uint8", "all"])
     ap.add_argument("--sizes", default="4096,8192,16384")
     ap.add_argument("--variants", default="")
     ap.add_argument("--reps", type=int, default=5)
@@ -56,7 +56,7 @@ def main():
                       f"({100*tf/PEAK['float']:5.1f}% of 157.3)  best {2.0*s**3/best/1e12:7.2f} TF", flush=True)
     else:
         table = {"f64": ("double", "Multiply", "Add"), "f16": ("half", "Multiply", "Add"),
-                 "minplus": ("float", "Add", "Min")}
+                 "minplus": ("float", "Add", "Min"), "uint8": ("uint8_t", "Multiply", "Add")}
         for key in ([args.what] if args.what != "all" else list(table)):
             dtype, mp, rd = table[key]
             for s in sizes:
