@@ -1,16 +1,26 @@
 #!/usr/bin/env python3
-"""bench.py -- BASELINE.json's metric on its config: fp32 GEMM N=K=M=16384 per MI355X
-("float 16384x16384x16384 on 1 MI355X, MFMA fp32, LDS-tiled outer product"), GFLOP/s and fraction of
-the fp32 MFMA peak; with --gpus G the rows of C are split into G slabs, one process per GPU, B
-replicated, no data-path collective (weak scaling: every rank multiplies its own 16384-row slab,
-i.e. the job is (G*16384) x 16384 x 16384 -- at G=4 exactly BASELINE's 65536x16384x16384).
+"""bench.py -- BASELINE.json's metric on its config.
+
+N = 1 (default):  fp32 GEMM N=K=M=16384 on one MI355X ("float 16384x16384x16384 on 1 MI355X, MFMA
+                  fp32, LDS-tiled outer product", BASELINE configs[1]): GFLOP/s and fraction of the
+                  fp32 MFMA peak.  The same JSON line carries a "workloads" array with the other
+                  single-GPU BASELINE configs (half 32768^3, double 16384^3, min-plus 8192^3, plus
+                  uint8 32768^3 and the 65536 x 16384 x 16384 job on ONE GPU), a few steps each, so
+                  that they are timed by the driver too.
+N > 1:            one process per GPU (python -m torch.distributed.run ...), rows of C split over
+                  the ranks with gemm_hls_amd.partition.row_slab, B replicated, NO data-path
+                  collective (the control plane -- barrier and max over ranks -- is the only
+                  communication).  --scaling strong (default): the FIXED job BASELINE configs[4]
+                  names, float 65536 x 16384 x 16384, split along N across the G ranks (8192 rows
+                  per GPU at G = 8).  --scaling weak: every rank owns a 16384-row slab (the job
+                  grows with G).  The strong run also reports the weak figure ("weak_scaling").
 
 A step = one pass of the hot path (one mm_gemm_enqueue through the C ABI) over operands that are
 already resident in HBM.  Timing = W untimed steps, barrier + synchronize, EXACTLY K steps,
 synchronize + barrier, MAX over ranks.  GOp/s = 1e-9 * 2*N*K*M / t as host/RunHardware.cpp:174-180.
 
-One JSON line on rank 0; besides the contract keys it carries
-  roofline     the dominant kernel against the MFMA roof, from HIP events on the launch stream
+Besides the contract keys the line carries
+  roofline     the dominant kernel against its roof, from HIP events on the launch stream
   cpu_baseline the reference's OWN hlslib CPU-simulation path (oracle/_ref, compiled from the
                reference's kernel sources) timed on this host's cores on float 1024^3 (BASELINE C1)
 """
@@ -24,18 +34,22 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-PEAK_TFLOPS_F32_MFMA = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 SIZE = 16384
-# The default workload is BASELINE.json's metric (configs[1]).  The other single-GPU BASELINE
-# configs can be timed with --workload; they are parity-test cases, not the headline line.
-#            dtype     map         reduce  size   roof  peak (T op/s)  unit of the roof
+C5A_ROWS = 65536  # BASELINE configs[4]: float 65536 x 16384 x 16384 split along N
+# Roofs.  MFMA peaks: /opt/skills/guides/MI355X_MICROARCH.md (dense); fp64 78.6 TF is the datasheet
+# figure, confirmed by tools/probes/probe_mfma_rate.hip (64 cycles per v_mfma_f64_16x16x4_f64).
+# min-plus: SURVEY.md 8(d)'s VALU ceiling, 256 CU x 4 SIMD x 32 lanes x 2.4 GHz = 78.6 T lane-ops/s
+# counting add + min as 2 operations; tools/probes/probe_valu_rate.hip measures the instruction mix
+# the kernel actually issues (2 v_add + 1 v_min3 per 4 operations) at the delivered clock.
+#            dtype     map         reduce  size   roof  peak (T op/s)
 WORKLOADS = {
     "float": ("float", "Multiply", "Add", 16384, "mfma", 157.3),
     "half": ("half", "Multiply", "Add", 32768, "mfma", 2500.0),
     "double": ("double", "Multiply", "Add", 16384, "mfma", 78.6),
-    "minplus": ("float", "Add", "Min", 8192, "valu", 65.0),   # measured VALU issue ceiling for 2 add + 1 min3
+    "minplus": ("float", "Add", "Min", 8192, "valu", 78.6),
     "uint8": ("uint8_t", "Multiply", "Add", 32768, "mfma", 5000.0),
 }
+DTYPE_TAG = {"float": "f32", "half": "f16 (f32 accumulate)", "double": "f64", "uint8_t": "u8 (i32 accumulate)"}
 
 
 def cpu_baseline(sample_n=1024):
@@ -80,16 +94,91 @@ def cpu_baseline(sample_n=1024):
 
 
 def hbm_traffic_per_launch():
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*_traffic.json,
-    written by tools/pmc_traffic.py with the guide's gfx950 correction); None if not collected."""
+    """HBM-side bytes per launch of the headline kernel.  NOT measured in this run: rocprofv3's PMC
+    passes serialise and slow the kernel, so they are collected separately by tools/pmc_traffic.py
+    (separate --pmc FETCH_SIZE / WRITE_SIZE passes, the guide's gfx950 correction) and committed
+    under profiles/; this returns (bytes, source file) of the newest such file, or (None, None)."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
-    if not files:
-        return None
-    try:
-        return json.load(open(files[-1])).get("hbm_bytes_per_launch")
-    except Exception:
-        return None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")), key=os.path.getmtime)
+    for path in reversed(files):
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        if d.get("hbm_bytes_per_launch") and d.get("workload", "float") == "float":
+            return d["hbm_bytes_per_launch"], os.path.relpath(path, ROOT)
+    return None, None
+
+
+def timed_steps(g, torch, a, b, c, dtype, map_op, reduce_op, steps, warmup, barrier):
+    """W untimed steps, barrier + synchronize, EXACTLY `steps` steps, synchronize + barrier.
+    Returns (wall seconds of the timed region, sorted per-launch ms from events on the launch stream)."""
+    def step():
+        g.matmul(a, b, dtype, map_op, reduce_op, out=c)
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    t0 = time.perf_counter()
+    ev[0].record()
+    for i in range(steps):
+        step()
+        ev[i + 1].record()  # same stream as the launch: per-launch duration without host gaps
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    return elapsed, sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(steps))
+
+
+def alloc_fill(g, torch, dev, local_rank, dtype, rows, k, m, seed_a, seed_b):
+    tdt = g.torch_dtype(dtype)
+    a = torch.empty((rows, k), dtype=tdt, device=dev)
+    b = torch.empty((k, m), dtype=tdt, device=dev)
+    c = torch.empty((rows, m), dtype=tdt, device=dev)
+    L = g.lib()
+    # synthetic operands of the reference's distribution, generated in HBM
+    g._check(L.mm_fill_device(local_rank, g.DTYPES[dtype], a.data_ptr(), a.numel(), seed_a))
+    g._check(L.mm_fill_device(local_rank, g.DTYPES[dtype], b.data_ptr(), b.numel(), seed_b))
+    torch.cuda.set_device(local_rank)
+    return a, b, c
+
+
+def roofline_obj(dtype, roof, peak, rows, k, m, launch_ms):
+    avg_s = 1e-3 * sum(launch_ms) / len(launch_ms)
+    achieved = 2.0 * rows * k * m / avg_s / 1e12
+    es = {"float": 4, "half": 2, "double": 8, "uint8_t": 1}[dtype]
+    return {"bound": roof, "achieved": round(achieved, 2), "peak": peak,
+            "unit": "TFLOP/s" if roof == "mfma" and dtype != "uint8_t" else "TOp/s",
+            "frac": round(achieved / peak, 4), "traffic": None,
+            "algorithmic_flops_per_launch": 2.0 * rows * k * m,
+            "algorithmic_bytes_per_launch": float((rows * k + k * m + rows * m) * es),
+            "avg_launch_ms": round(1e3 * avg_s, 4)}
+
+
+def extra_workloads(g, torch, dev, local_rank, steps=3):
+    """The other single-GPU BASELINE configs, a few steps each, in the same process."""
+    out = []
+    jobs = [("half", None), ("double", None), ("minplus", None), ("uint8", None), ("float", C5A_ROWS)]
+    for key, rows_override in jobs:
+        dtype, map_op, reduce_op, size, roof, peak = WORKLOADS[key]
+        rows = rows_override or size
+        k = m = size
+        try:
+            a, b, c = alloc_fill(g, torch, dev, local_rank, dtype, rows, k, m, 2000 + len(out), 3000 + len(out))
+            elapsed, launch_ms = timed_steps(g, torch, a, b, c, dtype, map_op, reduce_op, steps, 1, lambda: None)
+            value = 1e-9 * 2.0 * rows * k * m * steps / elapsed
+            out.append({"workload": f"{dtype} {rows}x{k}x{m} ({map_op},{reduce_op}) on 1 MI355X"
+                                    + ("; BASELINE configs[4]'s job without the split" if rows_override else ""),
+                        "kernel": g.kernel_name(g.make_config(dtype, map_op, reduce_op), rows, k, m),
+                        "dtype": DTYPE_TAG[dtype], "value": round(value, 1), "unit": "GOp/s", "steps": steps, "warmup": 1,
+                        "ms_per_step": round(1e3 * elapsed / steps, 4),
+                        "roofline": roofline_obj(dtype, roof, peak, rows, k, m, launch_ms)})
+        except Exception as exc:  # an extra must never take the headline line down with it
+            out.append({"workload": key, "error": repr(exc)})
+        a = b = c = None
+        torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -98,8 +187,13 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", choices=list(WORKLOADS), default="float")
-    ap.add_argument("--size", type=int, default=0, help="N=K=M per GPU (default: the workload's BASELINE size)")
+    ap.add_argument("--size", type=int, default=0, help="K = M (and N per GPU for weak scaling); default: the workload's BASELINE size")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                    help="N > 1 only. strong: a fixed job (--total-rows, default BASELINE's 65536 x 16384 x 16384) split "
+                         "along N; weak: every rank owns --size rows")
+    ap.add_argument("--total-rows", type=int, default=0, help="rows of C of the strong-scaling job")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the workloads[] / weak_scaling extras")
     args = ap.parse_args()
 
     import torch
@@ -124,6 +218,7 @@ def main():
     backend = os.environ.get("MM_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    dist = None
     if world > 1:
         import torch.distributed as dist
         # control plane only: barrier + max(t).  The data path has no collective.
@@ -142,55 +237,68 @@ def main():
         else:
             dist.init_process_group(backend=backend)
 
-    from gemm_hls_amd.partition import row_slab
-    n_total = args.size * world
-    row0, rows = row_slab(n_total, world, rank)
-    k = m = args.size
-    # synthetic operands of the reference's distribution, generated in HBM
-    tdt = g.torch_dtype(dtype)
-    a = torch.empty((rows, k), dtype=tdt, device=dev)
-    b = torch.empty((k, m), dtype=tdt, device=dev)
-    c = torch.empty((rows, m), dtype=tdt, device=dev)
-    L = g.lib()
-    g._check(L.mm_fill_device(local_rank, g.DTYPES[dtype], a.data_ptr(), a.numel(), 1000 + rank))
-    g._check(L.mm_fill_device(local_rank, g.DTYPES[dtype], b.data_ptr(), b.numel(), 7))
-    torch.cuda.set_device(local_rank)
-
-    def step():
-        g.matmul(a, b, dtype, map_op, reduce_op, out=c)
-
     def barrier():
         if world > 1:
             dist.barrier()
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    barrier()
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
-    t0 = time.perf_counter()
-    ev[0].record()
-    for i in range(args.steps):
-        step()
-        ev[i + 1].record()  # same stream as the launch: per-launch duration without host gaps
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    launch_ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps))
-    avg_launch_s = 1e-3 * sum(launch_ms) / len(launch_ms)
+        return float(t.item())
+
+    from gemm_hls_amd.partition import row_slab
+    k = m = args.size
+    headline = args.workload == "float" and args.size == SIZE
+
+    def run_job(n_total, seed_base):
+        """One timed region of the contract over the job of n_total rows; rank r owns row_slab(r)."""
+        row0, rows = row_slab(n_total, world, rank)
+        a, b, c = alloc_fill(g, torch, dev, local_rank, dtype, rows, k, m, seed_base + rank, 7)
+        elapsed, launch_ms = timed_steps(g, torch, a, b, c, dtype, map_op, reduce_op, args.steps, args.warmup, barrier)
+        elapsed = max_over_ranks(elapsed)
+        a = b = c = None
+        torch.cuda.empty_cache()
+        return rows, elapsed, launch_ms
+
+    if world == 1:
+        scaling = args.scaling
+        n_total = args.total_rows or args.size
+    elif args.scaling == "strong":
+        scaling = "strong"
+        n_total = args.total_rows or (C5A_ROWS if headline else 4 * args.size)
+    else:
+        scaling = "weak"
+        n_total = args.size * world
+    rows, elapsed, launch_ms = run_job(n_total, 1000)
+
+    weak = None
+    if world > 1 and scaling == "strong" and not args.no_extra:
+        w_rows, w_elapsed, w_launch = run_job(args.size * world, 5000)
+        weak = (w_rows, w_elapsed, w_launch)
 
     if rank == 0:
         flops_job = 2.0 * n_total * k * m
         value = 1e-9 * flops_job * args.steps / elapsed
-        achieved_tf = 2.0 * rows * k * m / avg_launch_s / 1e12
-        headline = args.workload == "float"
+        rl = roofline_obj(dtype, roof, peak, rows, k, m, launch_ms)
+        if headline and world == 1 and n_total == SIZE:
+            rl["traffic"], rl["traffic_source"] = hbm_traffic_per_launch()
+            if rl["traffic"] is not None:
+                rl["traffic_note"] = ("HBM-side bytes per launch replayed from the committed rocprofv3 PMC passes named in "
+                                      "traffic_source (collected by tools/pmc_traffic.py), not measured in this run")
+        if world == 1:
+            what = f"{dtype} {n_total}x{k}x{m} ({map_op},{reduce_op}) on 1 MI355X" + ("; BASELINE configs[1]" if headline else "")
+        elif scaling == "strong":
+            what = (f"{dtype} {n_total}x{k}x{m} ({map_op},{reduce_op}) split along N over {world} MI355X "
+                    f"({rows} rows on rank 0), B replicated, no collective"
+                    + ("; BASELINE configs[4]" if (headline and n_total == C5A_ROWS) else ""))
+        else:
+            what = (f"{dtype} {n_total}x{k}x{m} ({map_op},{reduce_op}): {args.size} rows per GPU over {world} MI355X, "
+                    "B replicated, no collective")
         out = {
             "metric": ("GFLOP/s, fp32 GEMM N=K=M=16384 per MI355X (tiled outer-product C=A.B), and % of fp32 MFMA peak"
-                       if headline else f"GOp/s, {dtype} ({map_op},{reduce_op}) N=K=M={args.size} per MI355X"),
+                       if headline else f"GOp/s, {dtype} ({map_op},{reduce_op}) K=M={args.size} per MI355X"),
             "value": round(value, 1),
             "unit": "GFLOP/s",
             "n_gpus": world,
@@ -198,22 +306,25 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
-            "dtype": {"float": "f32", "half": "f16 (f32 accumulate)", "double": "f64", "uint8_t": "u8 (i32 accumulate)"}[dtype],
+            "dtype": DTYPE_TAG[dtype],
             "data": "synthetic: uniform [1,10) (the reference generator's distribution), generated on device",
             "pct_of_mfma_peak": round(100.0 * value / 1e3 / (peak * world), 2),
-            "config": {"workload": f"{dtype} {n_total}x{k}x{m} ({map_op},{reduce_op}), rows of C split over {world} GPU(s), "
-                                   "B replicated, no collective" + ("; BASELINE configs[1] per GPU" if headline else ""),
+            "config": {"workload": what,
                        "kernel": g.kernel_name(g.make_config(dtype, map_op, reduce_op), rows, k, m),
-                       "rows_per_gpu": rows},
-            "roofline": {"bound": roof, "achieved": round(achieved_tf, 2), "peak": peak,
-                         "unit": "TFLOP/s" if roof == "mfma" and dtype != "uint8_t" else "TOp/s",
-                         "frac": round(achieved_tf / peak, 4),
-                         "traffic": hbm_traffic_per_launch() if (headline and args.size == SIZE) else None,
-                         "algorithmic_flops_per_launch": 2.0 * rows * k * m,
-                         "avg_launch_ms": round(1e3 * avg_launch_s, 4)},
+                       "rows_total": n_total, "rows_per_gpu": rows},
+            "roofline": rl,
         }
+        if weak is not None:
+            w_rows, w_elapsed, w_launch = weak
+            out["weak_scaling"] = {
+                "workload": f"{dtype} {args.size * world}x{k}x{m}: {args.size} rows per GPU over {world} MI355X",
+                "value": round(1e-9 * 2.0 * args.size * world * k * m * args.steps / w_elapsed, 1), "unit": "GFLOP/s",
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * w_elapsed / args.steps, 4),
+                "roofline": roofline_obj(dtype, roof, peak, w_rows, k, m, w_launch)}
+        if world == 1 and headline and not args.no_extra:
+            out["workloads"] = extra_workloads(g, torch, dev, local_rank)
         if world == 1 and not args.no_cpu_baseline and headline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -22,7 +22,8 @@ PATH_AUTO, PATH_ORDERED = 0, 1
 EXPORTS = ["mm_init", "mm_alloc", "mm_free", "mm_copy_to_device", "mm_copy_to_host",
            "mm_fill_device", "mm_gemm_launch", "mm_gemm_enqueue", "mm_gemm_multi_device",
            "MatrixMultiplicationKernel", "mm_set_default_config", "mm_dtype_size",
-           "mm_config_supported", "mm_kernel_name", "mm_kernel_info", "mm_last_error"]
+           "mm_config_supported", "mm_kernel_name", "mm_kernel_info", "mm_last_error",
+           "mm_gemm_host", "mm_tuning_set", "mm_tuning_get"]
 
 
 class MMError(RuntimeError):
@@ -32,6 +33,14 @@ class MMError(RuntimeError):
 class Config(ctypes.Structure):
     _fields_ = [("dtype", ctypes.c_int), ("map_op", ctypes.c_int), ("reduce_op", ctypes.c_int),
                 ("path", ctypes.c_int), ("layout_a", ctypes.c_int)]
+
+
+class KernelInfo(ctypes.Structure):  # mm_kernel_info_t
+    _fields_ = [("tile_n", ctypes.c_uint), ("tile_m", ctypes.c_uint), ("tile_k", ctypes.c_uint),
+                ("wavefronts", ctypes.c_uint), ("inst_n", ctypes.c_uint), ("inst_m", ctypes.c_uint),
+                ("inst_k", ctypes.c_uint), ("ops_per_clk_per_cu", ctypes.c_double),
+                ("compute_units", ctypes.c_uint), ("max_clock_mhz", ctypes.c_double),
+                ("measured_issue_efficiency", ctypes.c_double)]
 
 
 _lib = None
@@ -64,7 +73,11 @@ def lib():
         L.mm_config_supported.argtypes = [cfgp]
         L.mm_kernel_name.argtypes = [cfgp, u, u, u]
         L.mm_kernel_name.restype = ctypes.c_char_p
+        L.mm_kernel_info.argtypes = [cfgp, u, u, u, ctypes.POINTER(KernelInfo)]
         L.mm_last_error.restype = ctypes.c_char_p
+        L.mm_gemm_host.argtypes = [cfgp, vp, vp, vp, u, u, u]
+        L.mm_tuning_set.argtypes = [ctypes.c_char_p, i]
+        L.mm_tuning_get.argtypes = [ctypes.c_char_p, ctypes.POINTER(i)]
         _lib = L
     return _lib
 
@@ -86,6 +99,23 @@ def device_count():
 
 def kernel_name(cfg, n, k, m):
     return lib().mm_kernel_name(ctypes.byref(cfg), n, k, m).decode()
+
+
+def set_tuning(name, value):
+    """Tuning knob of the library ("f32_variant", "f16_variant", "band_rows", ...; -1 = default)."""
+    _check(lib().mm_tuning_set(name.encode(), int(value)))
+
+
+def get_tuning(name):
+    v = ctypes.c_int(0)
+    _check(lib().mm_tuning_get(name.encode(), ctypes.byref(v)))
+    return v.value
+
+
+def kernel_info(cfg, n, k, m):
+    info = KernelInfo()
+    _check(lib().mm_kernel_info(ctypes.byref(cfg), n, k, m, ctypes.byref(info)))
+    return info
 
 
 _TORCH_DTYPES = None
@@ -110,18 +140,30 @@ def matmul(a, b, dtype="float", map_op="Multiply", reduce_op="Add", path=PATH_AU
     import torch
     if not (a.is_cuda and b.is_cuda):
         raise MMError("matmul needs device tensors: there is no CPU path")
-    assert a.is_contiguous() and b.is_contiguous()
+    if a.device != b.device:
+        raise MMError(f"operands live on different devices: {a.device} and {b.device}")
     tdt = torch_dtype(dtype)
-    assert a.dtype == tdt and b.dtype == tdt, (a.dtype, b.dtype, tdt)
+    if not (a.is_contiguous() and b.is_contiguous()):
+        raise MMError("matmul needs contiguous (row-major) operands")
+    if a.dtype != tdt or b.dtype != tdt:
+        raise MMError(f"operand dtypes {a.dtype}, {b.dtype} do not match Data_t={dtype} ({tdt})")
+    if a.dim() != 2 or b.dim() != 2:
+        raise MMError("matmul takes 2-D operands")
     k, m = b.shape
     n = a.shape[1] if transposed_a else a.shape[0]
-    assert (a.shape[0] if transposed_a else a.shape[1]) == k
+    if (a.shape[0] if transposed_a else a.shape[1]) != k:
+        raise MMError(f"inner dimensions differ: A {tuple(a.shape)}{' (K x N)' if transposed_a else ''}, B {tuple(b.shape)}")
     if out is None:
         out = torch.empty((n, m), dtype=tdt, device=a.device)
+    elif (tuple(out.shape) != (n, m) or out.dtype != tdt or out.device != a.device or not out.is_contiguous()):
+        raise MMError(f"out must be a contiguous {tdt} tensor of shape {(n, m)} on {a.device}; got "
+                      f"{tuple(out.shape)}, {out.dtype}, {out.device}, contiguous={out.is_contiguous()}")
     cfg = make_config(dtype, map_op, reduce_op, path, transposed_a)
-    stream = torch.cuda.current_stream(a.device).cuda_stream
-    _check(lib().mm_gemm_enqueue(ctypes.c_void_p(stream), ctypes.byref(cfg), a.data_ptr(), b.data_ptr(),
-                                 out.data_ptr(), n, k, m))
+    # mm_gemm_enqueue launches on the CURRENT device: make that the operands' device
+    with torch.cuda.device(a.device):
+        stream = torch.cuda.current_stream(a.device).cuda_stream
+        _check(lib().mm_gemm_enqueue(ctypes.c_void_p(stream), ctypes.byref(cfg), a.data_ptr(), b.data_ptr(),
+                                     out.data_ptr(), n, k, m))
     return out
 
 

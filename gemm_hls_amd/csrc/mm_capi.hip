@@ -4,11 +4,13 @@
 // reference's own entry point MatrixMultiplicationKernel (kernel/Top.cpp:6-18).
 // There is no CPU compute path in this file or anywhere in this library.
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -37,29 +39,61 @@ int hip_fail(hipError_t e, const char *what) {
     if (e_ != hipSuccess) return hip_fail(e_, #call);  \
   } while (0)
 
-int g_device_count = -1;  // -1: not initialised
-mm_config_t g_default_cfg = {MM_DTYPE_F32, MM_OP_MULTIPLY, MM_OP_ADD, MM_PATH_AUTO, MM_A_ROW_MAJOR};
+// ---- process-wide state: initialised exactly once, read-only afterwards (safe for concurrent
+// calls from any number of host threads; g_error above is per thread) -------------------------
+std::once_flag g_init_once;
+int g_device_count = 0;
+int g_init_status = MM_ERR_NO_DEVICE;
+char g_init_error[512] = "";
 
-int ensure_init() {
-  if (g_device_count >= 0) return g_device_count > 0 ? MM_OK : fail(MM_ERR_NO_DEVICE, "no gfx950 device");
+void init_once() {
+  auto init_fail = [](const char *fmt, auto... args) {
+    snprintf(g_init_error, sizeof(g_init_error), fmt, args...);
+    g_device_count = 0;
+    g_init_status = MM_ERR_NO_DEVICE;
+  };
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
-  if (e != hipSuccess || n <= 0) {
-    g_device_count = 0;
-    return fail(MM_ERR_NO_DEVICE, "hipGetDeviceCount: %s; this library needs an MI355X (gfx950), there is no CPU fallback",
-                e == hipSuccess ? "0 devices" : hipGetErrorString(e));
-  }
+  if (e != hipSuccess || n <= 0)
+    return init_fail("hipGetDeviceCount: %s; this library needs an MI355X (gfx950), there is no CPU fallback",
+                     e == hipSuccess ? "0 devices" : hipGetErrorString(e));
+  // device indices are HIP's, so every visible device must be usable (mask others out with
+  // HIP_VISIBLE_DEVICES); a mixed box is reported, not half-used.
   for (int d = 0; d < n; ++d) {
     hipDeviceProp_t prop;
-    MM_HIP(hipGetDeviceProperties(&prop, d));
-    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
-      g_device_count = 0;
-      return fail(MM_ERR_NO_DEVICE, "device %d is %s; the kernels in this library are built for gfx950 only", d,
-                  prop.gcnArchName);
-    }
+    e = hipGetDeviceProperties(&prop, d);
+    if (e != hipSuccess) return init_fail("hipGetDeviceProperties(%d): %s", d, hipGetErrorString(e));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+      return init_fail("device %d is %s; the kernels in this library are built for gfx950 only "
+                       "(hide other devices with HIP_VISIBLE_DEVICES)", d, prop.gcnArchName);
   }
   g_device_count = n;
-  return MM_OK;
+  g_init_status = MM_OK;
+}
+
+int ensure_init() {
+  std::call_once(g_init_once, init_once);
+  return g_init_status == MM_OK ? MM_OK : fail(g_init_status, "%s", g_init_error);
+}
+
+std::mutex g_default_cfg_mutex;
+mm_config_t g_default_cfg = {MM_DTYPE_F32, MM_OP_MULTIPLY, MM_OP_ADD, MM_PATH_AUTO, MM_A_ROW_MAJOR};
+mm_config_t default_cfg() {
+  std::lock_guard<std::mutex> lock(g_default_cfg_mutex);
+  return g_default_cfg;
+}
+
+// ---- tuning knobs: environment read once, then only mm_tuning_set() changes them --------------
+std::once_flag g_tuning_once;
+std::atomic<int> g_tuning[mm::TUNE_COUNT];
+const char *const kTuneName[mm::TUNE_COUNT] = {"f32_variant", "f64_variant", "f16_variant", "i8_variant", "band_rows"};
+const char *const kTuneEnv[mm::TUNE_COUNT] = {"MM_F32_VARIANT", "MM_F64_VARIANT", "MM_F16_VARIANT", "MM_I8_VARIANT",
+                                              "MM_BAND_ROWS"};
+void tuning_init() {
+  for (int i = 0; i < mm::TUNE_COUNT; ++i) {
+    const char *e = getenv(kTuneEnv[i]);
+    g_tuning[i].store((e && *e) ? atoi(e) : -1, std::memory_order_relaxed);
+  }
 }
 
 int check_device(int device) {
@@ -79,37 +113,50 @@ bool valid_cfg(const mm_config_t *cfg) {
 
 // fp32 geometry: 256x256x16, 8 wavefronts, accumulators flushed into C every 4096 k (146 TF at
 // 16384^3, max rel err 2.7e-6 over the full matrix: profiles/r01_f32_precision_full_matrix.txt).
-// MM_F32_VARIANT (re-read on every call) selects another one for sweeps: tools/sweep.py.
-// -1 = shape-adaptive choice among the flush-capable geometries (mm_mfma_f32.hip).
-int f32_variant() {
-  const char *e = getenv("MM_F32_VARIANT");
-  return (e && *e) ? atoi(e) : -1;
-}
+// The f32_variant knob selects another one for sweeps (tools/sweep.py); -1 = shape-adaptive choice
+// among the flush-capable geometries (mm_mfma_f32.hip).
+int f32_variant() { return mm::tuning(mm::TUNE_F32_VARIANT); }
 int f32_variant_for(const mm::Problem &p) {
   const int v = f32_variant();
   return v >= 0 ? v : (p.a_transposed ? 8 : mm::mfma_f32_auto_variant(p));
 }
 
-enum Family { FAM_ORDERED, FAM_VALU_TILE, FAM_MFMA_F32, FAM_MFMA_F64, FAM_MFMA_F16, FAM_MFMA_I8 };
+enum Family { FAM_ORDERED, FAM_VALU_TILE, FAM_MFMA_F32, FAM_MFMA_F64, FAM_MFMA_F16, FAM_MFMA_I8, FAM_HALF_WIDE };
 
 Family choose(const mm_config_t &cfg, const mm::Problem &p) {
   if (cfg.path == MM_PATH_ORDERED) return FAM_ORDERED;
   const bool mul_add = cfg.map_op == MM_OP_MULTIPLY && cfg.reduce_op == MM_OP_ADD;
   if (mul_add && cfg.dtype == MM_DTYPE_F32 && mm::mfma_f32_serves(p)) return FAM_MFMA_F32;
   if (mul_add && cfg.dtype == MM_DTYPE_F64 && mm::mfma_f64_serves(p)) return FAM_MFMA_F64;
-  if (mul_add && cfg.dtype == MM_DTYPE_F16 && mm::mfma_f16_serves(p)) return FAM_MFMA_F16;
+  // half (x,+) keeps ONE numerical contract under AUTO (exact products, f32 accumulation, one
+  // rounding): shapes the matrix-core kernel does not take run the wide-accumulate plain kernel,
+  // never the half-accumulating ones (which would overflow to inf beyond K ~ 2000 on [1,10) data)
+  if (mul_add && cfg.dtype == MM_DTYPE_F16) return mm::mfma_f16_serves(p) ? FAM_MFMA_F16 : FAM_HALF_WIDE;
   if (mul_add && (cfg.dtype == MM_DTYPE_I8 || cfg.dtype == MM_DTYPE_U8) && mm::mfma_i8_serves(p)) return FAM_MFMA_I8;
   return mm::valu_tile_serves(cfg, p) ? FAM_VALU_TILE : FAM_ORDERED;
 }
 
+// The fast families move 16 bytes per lane (global_load_lds_dwordx4, 16-B vector stores): their
+// operands must be 16-B aligned, which every allocator gives (hipMalloc 256 B; the reference's
+// host vectors are 4096-B aligned, include/Utility.h:48).  An offset view is refused loudly; the
+// ordered path takes any element-aligned pointer.
+bool aligned16(const mm::Problem &p) {
+  return (((uintptr_t)p.a | (uintptr_t)p.b | (uintptr_t)p.c) & 15u) == 0;
+}
+
 int dispatch(hipStream_t s, const mm_config_t &cfg, const mm::Problem &p) {
   if (p.n == 0 || p.m == 0) return MM_OK;  // nothing to write
+  const Family fam = choose(cfg, p);
+  if (fam != FAM_ORDERED && fam != FAM_HALF_WIDE && !aligned16(p))
+    return fail(MM_ERR_BAD_ARGUMENT, "a, b and c must be 16-byte aligned for the fast path (got %p, %p, %p); "
+                "use an aligned allocation or MM_PATH_ORDERED", p.a, p.b, p.c);
   int e;
-  switch (choose(cfg, p)) {
+  switch (fam) {
     case FAM_MFMA_F32: e = mm::launch_mfma_f32(s, p, f32_variant()); break;
     case FAM_MFMA_F64: e = mm::launch_mfma_f64(s, p); break;
     case FAM_MFMA_F16: e = mm::launch_mfma_f16(s, p); break;
     case FAM_MFMA_I8: e = mm::launch_mfma_i8(s, p); break;
+    case FAM_HALF_WIDE: e = mm::launch_half_wide(s, p); break;
     case FAM_VALU_TILE:
       e = mm::launch_valu_tile(s, cfg, p);
       if (e == mm::kErrNotSupported) e = mm::launch_ordered(s, cfg, p);  // still the GPU
@@ -130,11 +177,35 @@ int check_problem(const mm_config_t *cfg, const void *a, const void *b, void *c,
   return MM_OK;
 }
 
+// hipEvent_t with a destructor: no exit path of the timed launch can leak one
+struct Event {
+  hipEvent_t e = nullptr;
+  ~Event() { if (e) (void)hipEventDestroy(e); }
+};
+
 }  // namespace
+
+int mm::tuning(mm::Tunable t) {
+  std::call_once(g_tuning_once, tuning_init);
+  return g_tuning[t].load(std::memory_order_relaxed);
+}
 
 extern "C" {
 
 const char *mm_last_error(void) { return g_error; }
+
+int mm_tuning_set(const char *name, int value) {
+  std::call_once(g_tuning_once, tuning_init);
+  for (int i = 0; name && i < mm::TUNE_COUNT; ++i)
+    if (strcmp(name, kTuneName[i]) == 0) { g_tuning[i].store(value, std::memory_order_relaxed); return MM_OK; }
+  return fail(MM_ERR_BAD_ARGUMENT, "unknown tuning knob '%s'", name ? name : "(null)");
+}
+
+int mm_tuning_get(const char *name, int *value) {
+  for (int i = 0; name && value && i < mm::TUNE_COUNT; ++i)
+    if (strcmp(name, kTuneName[i]) == 0) { *value = mm::tuning((mm::Tunable)i); return MM_OK; }
+  return fail(MM_ERR_BAD_ARGUMENT, "unknown tuning knob '%s'", name ? name : "(null)");
+}
 
 size_t mm_dtype_size(mm_dtype_t dtype) {
   static const size_t sz[] = {4, 8, 2, 1, 1, 2, 2, 4, 4, 8, 8};
@@ -143,7 +214,7 @@ size_t mm_dtype_size(mm_dtype_t dtype) {
 
 int mm_init(int *device_count) {
   int rc = ensure_init();
-  if (device_count) *device_count = g_device_count > 0 ? g_device_count : 0;
+  if (device_count) *device_count = g_device_count;
   return rc;
 }
 
@@ -210,26 +281,21 @@ int mm_gemm_launch(int device, const mm_config_t *cfg, const void *a, const void
   rc = check_problem(cfg, a, b, c, n, k, m);
   if (rc) return rc;
   MM_HIP(hipSetDevice(device));
-  hipEvent_t start, stop;
-  MM_HIP(hipEventCreate(&start));
-  MM_HIP(hipEventCreate(&stop));
+  Event start, stop;
+  MM_HIP(hipEventCreate(&start.e));
+  MM_HIP(hipEventCreate(&stop.e));
   mm::Problem p{a, b, c, n, k, m, cfg->layout_a == MM_A_TRANSPOSED};
-  MM_HIP(hipEventRecord(start, nullptr));
+  MM_HIP(hipEventRecord(start.e, nullptr));
   rc = dispatch(nullptr, *cfg, p);
-  if (rc == MM_OK) {
-    hipError_t e = hipEventRecord(stop, nullptr);
-    if (e == hipSuccess) e = hipEventSynchronize(stop);
-    if (e != hipSuccess) rc = hip_fail(e, "kernel execution");
-  }
-  if (rc == MM_OK && elapsed_seconds) {
+  if (rc != MM_OK) return rc;
+  MM_HIP(hipEventRecord(stop.e, nullptr));
+  MM_HIP(hipEventSynchronize(stop.e));
+  if (elapsed_seconds) {
     float ms = 0.f;
-    hipError_t e = hipEventElapsedTime(&ms, start, stop);
-    if (e != hipSuccess) rc = hip_fail(e, "hipEventElapsedTime");
+    MM_HIP(hipEventElapsedTime(&ms, start.e, stop.e));
     *elapsed_seconds = 1e-3 * (double)ms;
   }
-  (void)hipEventDestroy(start);
-  (void)hipEventDestroy(stop);
-  return rc;
+  return MM_OK;
 }
 
 int mm_gemm_multi_device(int device_count, const mm_config_t *cfg, const void *a_host, const void *b_host,
@@ -268,13 +334,53 @@ int mm_gemm_multi_device(int device_count, const mm_config_t *cfg, const void *a
     MM_HIP_MD(hipSetDevice(g));
     MM_HIP_MD(hipStreamCreateWithFlags(&d.s, hipStreamNonBlocking));
     MM_HIP_MD(hipMalloc(&d.b, (size_t)k * m * es));
-    MM_HIP_MD(hipMemcpyAsync(d.b, b_host, (size_t)k * m * es, hipMemcpyHostToDevice, d.s));
     if (d.rows) {
       MM_HIP_MD(hipMalloc(&d.a, (size_t)d.rows * k * es));
       MM_HIP_MD(hipMalloc(&d.c, (size_t)d.rows * m * es));
+    }
+  }
+  // B crosses PCIe ONCE (host -> device 0) and is then fanned out device 0 -> device g over xGMI
+  // (every GPU has its own link to GPU 0, so the G-1 peer copies run concurrently), instead of G
+  // pageable host copies through one root complex; the A slabs go up meanwhile.  A device that
+  // cannot take the peer copy gets B from the host as before.
+  Event b_on_dev0;
+  MM_HIP_MD(hipSetDevice(0));
+  MM_HIP_MD(hipEventCreateWithFlags(&b_on_dev0.e, hipEventDisableTiming));
+  MM_HIP_MD(hipMemcpyAsync(devs[0].b, b_host, (size_t)k * m * es, hipMemcpyHostToDevice, devs[0].s));
+  MM_HIP_MD(hipEventRecord(b_on_dev0.e, devs[0].s));
+  for (int g = 0; g < device_count; ++g) {
+    Dev &d = devs[g];
+    MM_HIP_MD(hipSetDevice(g));
+    if (g > 0) {
+      int can = 0;
+      bool peer = hipDeviceCanAccessPeer(&can, g, 0) == hipSuccess && can;
+      if (peer) {
+        const hipError_t en = hipDeviceEnablePeerAccess(0, 0);
+        peer = en == hipSuccess || en == hipErrorPeerAccessAlreadyEnabled;
+        (void)hipGetLastError();  // "already enabled" is not an error of this call
+      }
+      if (peer) {
+        MM_HIP_MD(hipStreamWaitEvent(d.s, b_on_dev0.e, 0));
+        MM_HIP_MD(hipMemcpyPeerAsync(d.b, g, devs[0].b, 0, (size_t)k * m * es, d.s));
+      } else {
+        MM_HIP_MD(hipMemcpyAsync(d.b, b_host, (size_t)k * m * es, hipMemcpyHostToDevice, d.s));
+      }
+    }
+    if (d.rows)
       MM_HIP_MD(hipMemcpyAsync(d.a, (const char *)a_host + (size_t)d.row0 * k * es, (size_t)d.rows * k * es,
                                hipMemcpyHostToDevice, d.s));
-    }
+  }
+  for (int g = 0; g < device_count; ++g) { MM_HIP_MD(hipSetDevice(g)); MM_HIP_MD(hipStreamSynchronize(devs[g].s)); }
+  // untimed warm-up pass of the same launch: the first dispatch on a device loads the code object,
+  // opts the kernel into its LDS size and ramps the clocks; paying that outside the timed region
+  // makes this figure comparable with mm_gemm_launch's (whose callers warm up the same way)
+  for (int g = 0; g < device_count; ++g) {
+    Dev &d = devs[g];
+    if (!d.rows) continue;
+    MM_HIP_MD(hipSetDevice(g));
+    mm::Problem warm{d.a, d.b, d.c, d.rows, k, m, false};
+    rc = dispatch(d.s, *cfg, warm);
+    if (rc) { cleanup(); return rc; }
   }
   for (int g = 0; g < device_count; ++g) { MM_HIP_MD(hipSetDevice(g)); MM_HIP_MD(hipStreamSynchronize(devs[g].s)); }
   // timed region: common start -> every device complete (copies excluded, as RunHardware.cpp does)
@@ -303,6 +409,7 @@ int mm_gemm_multi_device(int device_count, const mm_config_t *cfg, const void *a
 
 int mm_set_default_config(const mm_config_t *cfg) {
   if (!valid_cfg(cfg)) return fail(MM_ERR_BAD_ARGUMENT, "invalid mm_config_t");
+  std::lock_guard<std::mutex> lock(g_default_cfg_mutex);
   g_default_cfg = *cfg;
   return MM_OK;
 }
@@ -373,8 +480,13 @@ static int mm_run_host_pointers(const mm_config_t &cfg, const void *a, const voi
   return MM_OK;
 }
 
+int mm_gemm_host(const mm_config_t *cfg, const void *a, const void *b, void *c, unsigned n, unsigned k, unsigned m) {
+  if (!valid_cfg(cfg)) return fail(MM_ERR_BAD_ARGUMENT, "invalid mm_config_t");
+  return mm_run_host_pointers(*cfg, a, b, c, n, k, m);
+}
+
 void MatrixMultiplicationKernel(const void *a, const void *b, void *c, unsigned n, unsigned k, unsigned m) {
-  const int rc = mm_run_host_pointers(g_default_cfg, a, b, c, n, k, m);
+  const int rc = mm_run_host_pointers(default_cfg(), a, b, c, n, k, m);
   if (rc) {
     fprintf(stderr, "MatrixMultiplicationKernel failed: %s\n", mm_last_error());
     abort();  // the reference's symbol returns void; failing silently would fake a result
@@ -391,6 +503,7 @@ const char *mm_kernel_name(const mm_config_t *cfg, unsigned n, unsigned k, unsig
     case FAM_MFMA_F64: return "mfma_f64";
     case FAM_MFMA_F16: return "mfma_f16";
     case FAM_MFMA_I8: return "mfma_i8";
+    case FAM_HALF_WIDE: return "ordered_wide_f16";
     case FAM_VALU_TILE: return "valu_tile";
     default: return "ordered";
   }

@@ -78,6 +78,7 @@ struct Problem {
 // Launchers (one translation unit each).  Return hipError_t as int; hipErrorNotSupported (801)
 // means "this family does not serve this (config, shape)".
 int launch_ordered(hipStream_t s, const mm_config_t &cfg, const Problem &p);
+int launch_half_wide(hipStream_t s, const Problem &p);  // half (x,+), f32 accumulate, any shape
 int launch_valu_tile(hipStream_t s, const mm_config_t &cfg, const Problem &p);
 bool valu_tile_serves(const mm_config_t &cfg, const Problem &p);
 int launch_mfma_f32(hipStream_t s, const Problem &p, int variant);
@@ -112,14 +113,26 @@ inline int ensure_dynamic_lds(const void *func, int bytes, unsigned long long &m
   return 0;
 }
 
+// Tuning knobs (sweeps and ablations only; defaults are the measured best).  Each one is read
+// ONCE from its environment variable when the library initialises and can be changed afterwards
+// through mm_tuning_set() -- the launch path itself never calls getenv.  -1 = unset.
+enum Tunable {
+  TUNE_F32_VARIANT = 0,  // MM_F32_VARIANT  geometry of the fp32 MFMA kernel (mm_mfma_f32.hip)
+  TUNE_F64_VARIANT,      // MM_F64_VARIANT
+  TUNE_F16_VARIANT,      // MM_F16_VARIANT
+  TUNE_I8_VARIANT,       // MM_I8_VARIANT
+  TUNE_BAND_ROWS,        // MM_BAND_ROWS    tile-rows per rasterisation band
+  TUNE_COUNT
+};
+int tuning(Tunable t);  // mm_capi.hip
+
 // Tile rasterisation: after the XCD remap, workgroups are ordered in bands of `band_rows` tile-rows
 // (column-major inside a band), so the 32 workgroups an XCD runs at once cover
 // band_rows x (32/band_rows) tiles and share A row-panels / B column-panels in that XCD's L2.
 // 4 measured best on the fp32 kernel (fabric fetch 30 GB per 16384^3 launch vs 51 GB at 8 and
-// 100 GB at 16; profiles/r01_band_rows_sweep.txt).  MM_BAND_ROWS overrides it for experiments.
+// 100 GB at 16; profiles/r01_band_rows_sweep.txt).
 inline unsigned band_rows() {
-  const char *e = getenv("MM_BAND_ROWS");
-  const int v = e ? atoi(e) : 0;
+  const int v = tuning(TUNE_BAND_ROWS);
   return v > 0 ? (unsigned)v : 4u;
 }
 

@@ -299,12 +299,12 @@ int mfma_f16_tile(const Problem &p) {  // 0: 256x256, 4: 128x256
 int launch_mfma_f16(hipStream_t s, const Problem &p) {
   if (!mfma_f16_serves(p)) return kErrNotSupported;
   if (p.a_transposed) return launch_h<GeoH, true>(s, p);
-  const char *v = getenv("MM_F16_VARIANT");  // tuning hook
-  if (v && atoi(v) == 1) return launch_h<GeoH4>(s, p);
-  if (v && atoi(v) == 2) return launch_h<GeoH32x4>(s, p);
-  if (v && atoi(v) == 3) return launch_h<GeoH32x3>(s, p);
-  if (v && atoi(v) == 4) return launch_h<GeoHS>(s, p);
-  if (!v && mfma_f16_tile(p) == 4) return launch_h<GeoHS>(s, p);
+  const int v = tuning(TUNE_F16_VARIANT);  // tuning hook
+  if (v == 1) return launch_h<GeoH4>(s, p);
+  if (v == 2) return launch_h<GeoH32x4>(s, p);
+  if (v == 3) return launch_h<GeoH32x3>(s, p);
+  if (v == 4) return launch_h<GeoHS>(s, p);
+  if (v < 0 && mfma_f16_tile(p) == 4) return launch_h<GeoHS>(s, p);
   return launch_h<GeoH>(s, p);
 }
 

@@ -231,8 +231,8 @@ static int launch_d(hipStream_t s, const Problem &p) {
 }
 
 int mfma_f64_tile(const Problem &p) {  // 0: 256x128, 1: 128x128
-  const char *e = getenv("MM_F64_VARIANT");
-  if (e && *e) return atoi(e);
+  const int v = tuning(TUNE_F64_VARIANT);
+  if (v >= 0) return v;
   static const TileCandidate cands[] = {{0, 256, 128, 1, 1.00}, {1, 128, 128, 2, 0.74}};
   return pick_tile(cands, 2, p.n, p.m);
 }

@@ -15,7 +15,11 @@ constexpr int kTile = 64;   // outputs per workgroup edge
 constexpr int kBK = 16;     // k-slab staged through LDS
 constexpr int kPerThread = 4;
 
-template <typename T, int MAP, int RED, bool AT>
+// ACC is the accumulator type: T itself for the Naive contract; float for the one exception,
+// half (Multiply, Add) under MM_PATH_AUTO on shapes the matrix-core kernel does not take
+// ("ordered_wide_f16": exact products, f32 accumulation, ONE rounding to binary16 on store -- the
+// same contract as mfma_f16, so the AUTO path's half semantics do not change with the shape).
+template <typename T, int MAP, int RED, bool AT, typename ACC = T>
 __global__ __launch_bounds__(256) void ordered_kernel(const T *__restrict__ A, const T *__restrict__ B,
                                                       T *__restrict__ C, unsigned N, unsigned K,
                                                       unsigned M) {
@@ -25,11 +29,11 @@ __global__ __launch_bounds__(256) void ordered_kernel(const T *__restrict__ A, c
   const unsigned tx = tid % 16, ty = tid / 16;
   const unsigned row0 = blockIdx.y * kTile, col0 = blockIdx.x * kTile;
 
-  T acc[kPerThread][kPerThread];
+  ACC acc[kPerThread][kPerThread];
 #pragma unroll
   for (int i = 0; i < kPerThread; ++i)
 #pragma unroll
-    for (int j = 0; j < kPerThread; ++j) acc[i][j] = Op<RED, T>::identity();
+    for (int j = 0; j < kPerThread; ++j) acc[i][j] = Op<RED, ACC>::identity();
 
   for (unsigned k0 = 0; k0 < K; k0 += kBK) {
     // stage A: 64 rows x 16 k
@@ -62,7 +66,7 @@ __global__ __launch_bounds__(256) void ordered_kernel(const T *__restrict__ A, c
       for (int i = 0; i < kPerThread; ++i)
 #pragma unroll
         for (int j = 0; j < kPerThread; ++j)
-          acc[i][j] = Op<RED, T>::apply(acc[i][j], Op<MAP, T>::apply(av[i], bv[j]));
+          acc[i][j] = Op<RED, ACC>::apply(acc[i][j], Op<MAP, ACC>::apply((ACC)av[i], (ACC)bv[j]));
     }
     __syncthreads();
   }
@@ -73,7 +77,7 @@ __global__ __launch_bounds__(256) void ordered_kernel(const T *__restrict__ A, c
 #pragma unroll
     for (int j = 0; j < kPerThread; ++j) {
       const unsigned gc = col0 + tx + 16 * j;
-      if (gc < M) C[(size_t)gr * M + gc] = acc[i][j];
+      if (gc < M) C[(size_t)gr * M + gc] = (T)acc[i][j];
     }
   }
 }
@@ -116,6 +120,18 @@ int launch_map(hipStream_t s, const mm_config_t &cfg, const Problem &p) {
 }
 
 }  // namespace
+
+int launch_half_wide(hipStream_t s, const Problem &p) {
+  if (p.n == 0 || p.m == 0) return 0;
+  dim3 grid((p.m + kTile - 1) / kTile, (p.n + kTile - 1) / kTile);
+  if (p.a_transposed)
+    hipLaunchKernelGGL((ordered_kernel<half_t, MM_OP_MULTIPLY, MM_OP_ADD, true, float>), grid, dim3(256), 0, s,
+                       (const half_t *)p.a, (const half_t *)p.b, (half_t *)p.c, p.n, p.k, p.m);
+  else
+    hipLaunchKernelGGL((ordered_kernel<half_t, MM_OP_MULTIPLY, MM_OP_ADD, false, float>), grid, dim3(256), 0, s,
+                       (const half_t *)p.a, (const half_t *)p.b, (half_t *)p.c, p.n, p.k, p.m);
+  return (int)hipGetLastError();
+}
 
 int launch_ordered(hipStream_t s, const mm_config_t &cfg, const Problem &p) {
   switch (cfg.dtype) {

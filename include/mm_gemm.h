@@ -24,7 +24,10 @@ extern "C" {
 typedef enum {
   MM_DTYPE_F32 = 0, /* float          */
   MM_DTYPE_F64 = 1, /* double         */
-  MM_DTYPE_F16 = 2, /* half (IEEE binary16; f32 accumulate, one rounding on store) */
+  MM_DTYPE_F16 = 2, /* half (IEEE binary16).  (Multiply, Add) under MM_PATH_AUTO: exact products,
+                       f32 accumulation, ONE rounding on store, for EVERY shape (matrix cores when
+                       K % 16 == 0 and M % 8 == 0, a plain wide-accumulate kernel otherwise);
+                       MM_PATH_ORDERED accumulates in binary16 exactly like the reference */
   MM_DTYPE_I8 = 3,  /* int8_t         */
   MM_DTYPE_U8 = 4,  /* uint8_t        */
   MM_DTYPE_I16 = 5, /* short          */
@@ -105,7 +108,12 @@ int mm_fill_device(int device, mm_dtype_t dtype, void *device_ptr, size_t elemen
  *      fully predicated kernel rather than rejected. ----------------------------------------- */
 
 /* Blocking launch on `device`; *elapsed_seconds (may be NULL) receives the kernel time
- * measured with HIP events on the launch stream == ExecuteTask()'s elapsed.first. */
+ * measured with HIP events on the launch stream == ExecuteTask()'s elapsed.first.
+ * MM_PATH_AUTO needs a, b and c 16-byte aligned (any allocator's result; the reference's host
+ * vectors are 4096-byte aligned, include/Utility.h:48) and returns MM_ERR_BAD_ARGUMENT for an
+ * offset view; MM_PATH_ORDERED takes any element-aligned pointer.
+ * Thread safety: every entry point may be called concurrently from several host threads (on the
+ * same or on different devices / streams); mm_last_error() is per thread. */
 int mm_gemm_launch(int device, const mm_config_t *cfg, const void *a_dev, const void *b_dev,
                    void *c_dev, unsigned size_n, unsigned size_k, unsigned size_m,
                    double *elapsed_seconds);
@@ -137,6 +145,13 @@ int mm_gemm_multi_device(int device_count, const mm_config_t *cfg, const void *a
 void MatrixMultiplicationKernel(const void *a, const void *b, void *c, unsigned size_n,
                                 unsigned size_k, unsigned size_m);
 int mm_set_default_config(const mm_config_t *cfg);
+/* The same host-pointer call with an explicit configuration and a status instead of abort().
+ * This is what the build-time-configured kernel shim (gemm_hls_amd/host/KernelShim.cpp: one
+ * library per MM_DATA_TYPE / MM_MAP_OP / MM_REDUCE_OP / MM_TRANSPOSED_A / MM_DYNAMIC_SIZES choice,
+ * exporting the reference's exact symbol incl. the 3-pointer static-size form,
+ * include/MatrixMultiplication.h:155-171) forwards to. */
+int mm_gemm_host(const mm_config_t *cfg, const void *a, const void *b, void *c, unsigned size_n,
+                 unsigned size_k, unsigned size_m);
 
 /* ---- introspection ------------------------------------------------------------------------ */
 size_t mm_dtype_size(mm_dtype_t dtype);
@@ -160,6 +175,13 @@ typedef struct {
 } mm_kernel_info_t;
 int mm_kernel_info(const mm_config_t *cfg, unsigned size_n, unsigned size_k, unsigned size_m,
                    mm_kernel_info_t *info);
+/* Tuning knobs for sweeps and ablations ("f32_variant", "f64_variant", "f16_variant",
+ * "i8_variant", "band_rows"; -1 = the library's own choice).  Each is initialised ONCE from its
+ * environment variable (MM_F32_VARIANT, ...) and changed only through this call afterwards; the
+ * launch path never reads the environment.  No reference counterpart (the reference's tile sizes
+ * are CMake cache variables, CMakeLists.txt:18-20). */
+int mm_tuning_set(const char *name, int value);
+int mm_tuning_get(const char *name, int *value);
 /* Message of the last failing call on this thread (static or thread-local storage). */
 const char *mm_last_error(void);
 

@@ -30,8 +30,9 @@ def test_cpu_baseline_object_shape():
 
 def test_traffic_comes_from_committed_profile():
     b = _bench()
-    t = b.hbm_traffic_per_launch()
+    t, source = b.hbm_traffic_per_launch()
     assert t is None or t > 3.2e9  # never below the compulsory bytes of fp32 16384^3
+    assert t is None or (source.startswith("profiles/") and os.path.exists(os.path.join(ROOT, source)))
     files = [f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_traffic.json")]
     assert files, "profiles/*_traffic.json missing"
     r = json.load(open(os.path.join(ROOT, "profiles", sorted(files)[-1])))
@@ -41,4 +42,24 @@ def test_traffic_comes_from_committed_profile():
 def test_constants_match_baseline():
     b = _bench()
     base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
-    assert str(b.SIZE) in base["metric"] and b.PEAK_TFLOPS_F32_MFMA == 157.3
+    assert str(b.SIZE) in base["metric"] and b.WORKLOADS["float"][5] == 157.3
+    # the strong-scaling job is BASELINE configs[4]'s: float 65536 x 16384 x 16384 split along N
+    assert f"{b.C5A_ROWS}" in base["configs"][4] and b.WORKLOADS["float"][3] == b.SIZE
+    # every other single-GPU BASELINE config has a workloads[] entry at its size
+    assert b.WORKLOADS["half"][3] == 32768 and "32768" in base["configs"][2]
+    assert b.WORKLOADS["double"][3] == 16384 and "double" in base["configs"][3]
+    assert b.WORKLOADS["minplus"][3] == 8192 and "8192" in base["configs"][4]
+
+
+def test_default_mode_for_more_than_one_gpu_is_baselines_fixed_job():
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert 'default="strong"' in src and "C5A_ROWS if headline" in src
+
+
+def test_strong_split_of_the_baseline_job_is_tile_aligned_and_balanced():
+    from gemm_hls_amd.partition import row_slab
+    b = _bench()
+    for world in (1, 2, 4, 8):
+        slabs = [row_slab(b.C5A_ROWS, world, r) for r in range(world)]
+        assert sum(rows for _, rows in slabs) == b.C5A_ROWS
+        assert all(rows == b.C5A_ROWS // world and row0 % 256 == 0 for row0, rows in slabs)

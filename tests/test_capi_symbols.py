@@ -77,3 +77,43 @@ def test_bad_arguments_are_rejected_before_touching_a_device():
     assert g.lib().mm_config_supported(ctypes.byref(cfg)) == 0
     assert g.lib().mm_set_default_config(ctypes.byref(cfg)) != 0
     assert b"invalid" in g.lib().mm_last_error()
+
+
+def test_half_auto_path_never_falls_back_to_half_accumulation():
+    """K % 16 != 0 (or M % 8 != 0) must not silently change half (x,+) semantics."""
+    assert g.kernel_name(g.make_config("half"), 512, 4096, 512) == "mfma_f16"
+    assert g.kernel_name(g.make_config("half"), 512, 4104, 512) == "ordered_wide_f16"
+    assert g.kernel_name(g.make_config("half"), 512, 4096, 516) == "ordered_wide_f16"
+    assert g.kernel_name(g.make_config("half", path=g.PATH_ORDERED), 512, 4104, 512) == "ordered"
+    assert g.kernel_name(g.make_config("half", "Add", "Min"), 512, 4104, 512) == "valu_tile"
+
+
+def test_tuning_knobs_are_library_state_not_environment(monkeypatch):
+    assert g.get_tuning("f32_variant") == -1
+    monkeypatch.setenv("MM_F32_VARIANT", "3")            # too late: the environment is read once
+    assert g.get_tuning("f32_variant") == -1
+    try:
+        g.set_tuning("f32_variant", 3)
+        assert g.get_tuning("f32_variant") == 3
+        assert g.kernel_name(g.make_config("float"), 4096, 4096, 4096) == "mfma_f32_256x256x16_w8"
+    finally:
+        g.set_tuning("f32_variant", -1)
+    assert g.kernel_name(g.make_config("float"), 16384, 16384, 16384) == "mfma_f32_256x256x16_w8_flush4096"
+    with pytest.raises(g.MMError, match="unknown tuning knob"):
+        g.set_tuning("no_such_knob", 1)
+
+
+def test_tuning_environment_is_read_at_first_use():
+    import subprocess
+    import sys
+    code = ("import gemm_hls_amd as g; print(g.get_tuning('f32_variant'), g.get_tuning('band_rows'), "
+            "g.kernel_name(g.make_config('float'), 4096, 4096, 4096))")
+    env = dict(os.environ, MM_F32_VARIANT="13", MM_BAND_ROWS="8", PYTHONPATH=ROOT)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout.split()
+    assert out == ["13", "8", "mfma_f32_128x256x32_w4_flush4096"]
+
+
+def test_kernel_info_binding():
+    info = g.kernel_info(g.make_config("float"), 16384, 16384, 16384)
+    assert (info.tile_n, info.tile_m, info.tile_k, info.wavefronts) == (256, 256, 16, 8)
+    assert info.compute_units == 256 and info.max_clock_mhz == 2400.0

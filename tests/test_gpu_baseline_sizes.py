@@ -1,0 +1,233 @@
+"""Parity at BASELINE.json's FULL sizes for the configs that are not the fp32 headline
+(tests/test_gpu_parity.py covers float 16384^3 and 65536 x 16384 x 16384):
+
+    C3  half   32768^3   (Multiply, Add)  mfma_f16
+    C4  double 16384^3   (Multiply, Add)  mfma_f64
+    C5b float  8192^3    (Add, Min)       valu_tile, the non-MFMA path
+
+A CPU oracle cannot finish these sizes, so each test checks (i) sampled rows x sampled column
+blocks of the device result against the CPU oracle (tests/_oracle.py: Naive, include/Utility.h:18-42;
+wide-accumulate Naive for half; fp64 BLAS for double) and (ii) size-independent properties over the
+WHOLE output: the fast family against the independently written k-ordered kernel where the semiring
+is order-independent, exact power-of-two linearity, row-permutation equivariance, determinism.
+Also here: mixed-sign fp32 with a normwise bound (the seeded reference data is all-positive, which
+cannot see a sign or cancellation bug in a fragment path).
+
+Comparison rule and tolerances: test/TestSimulation.cpp:75-92; BASELINE.json north_star (fp32 1e-5,
+integer / min-plus semirings bit-exact)."""
+import numpy as np
+import pytest
+
+import _oracle
+import gemm_hls_amd as g
+
+pytestmark = pytest.mark.gpu
+
+
+def _device_fill(dtype, shape, seed):
+    import torch
+    t = torch.empty(shape, dtype=g.torch_dtype(dtype), device="cuda:0")
+    assert g.lib().mm_fill_device(0, g.DTYPES[dtype], t.data_ptr(), t.numel(), seed) == 0
+    return t
+
+
+def _sample(n, m, block=96):
+    """Rows and column blocks that straddle tile, band and XCD-chunk boundaries, first and last."""
+    rows = sorted({0, 1, 127, 128, 255, 256, n // 2 - 1, n // 2, n - 257, n - 2, n - 1})
+    starts = sorted({0, 256 - block // 2, m // 2 - block // 2, m - 512 - block // 2, m - block})
+    cols = np.concatenate([np.arange(s, s + block) for s in starts])
+    return rows, cols
+
+
+def _host_slices(a, b, c, rows, cols):
+    import torch
+    ci = torch.as_tensor(cols, device=a.device)
+    return (a[rows].cpu().numpy(), b[:, ci].contiguous().cpu().numpy(), c[rows][:, ci].contiguous().cpu().numpy())
+
+
+# ---- C5b: float (Add, Min) 8192^3 ----------------------------------------------------------------
+def test_minplus_8192_valu_tile_vs_ordered_and_naive():
+    import torch
+    n = k = m = 8192
+    a = _device_fill("float", (n, k), 31)
+    b = _device_fill("float", (k, m), 32)
+    assert g.kernel_name(g.make_config("float", "Add", "Min"), n, k, m) == "valu_tile"
+    c = g.matmul(a, b, "float", "Add", "Min")
+    c_ord = g.matmul(a, b, "float", "Add", "Min", path=g.PATH_ORDERED)
+    torch.cuda.synchronize()
+    # min over k of (a + b): every a + b is one rounding and min is exact, so any order gives the same bits
+    assert torch.equal(c, c_ord)
+    rows, cols = _sample(n, m)
+    ah, bh, ch = _host_slices(a, b, c, rows, cols)
+    assert np.array_equal(ch, _oracle.naive("float", "Add", "Min", ah, bh))
+    # tropical "linearity": adding a constant to A adds it to every output only up to rounding, but
+    # row-permutation equivariance and determinism are exact
+    perm = torch.randperm(n, device=a.device)
+    assert torch.equal(g.matmul(a[perm].contiguous(), b, "float", "Add", "Min"), c[perm])
+    assert torch.equal(g.matmul(a, b, "float", "Add", "Min"), c)
+
+
+# ---- C4: double (Multiply, Add) 16384^3 ------------------------------------------------------------
+def test_double_16384_sampled_rows_and_properties():
+    import torch
+    n = k = m = 16384
+    a = _device_fill("double", (n, k), 41)
+    b = _device_fill("double", (k, m), 42)
+    assert g.kernel_name(g.make_config("double"), n, k, m) == "mfma_f64"
+    c = g.matmul(a, b, "double")
+    torch.cuda.synchronize()
+    rows, cols = _sample(n, m)
+    ah, bh, ch = _host_slices(a, b, c, rows, cols)
+    blas = ah @ bh                                     # cblas_dgemm: the reference's ReferenceImplementation
+    bad, first, worst = _oracle.compare("double", ch, blas, 1e-12)
+    assert bad == 0, (first, worst)
+    # against a wider yardstick (long double accumulation of exact-in-long-double products)
+    exact = (ah[:4].astype(np.longdouble) @ bh.astype(np.longdouble))
+    assert np.max(np.abs(ch[:4] - exact) / exact) < 1e-13
+    # the k-ordered kernel on the same sampled rows (full width): same products, different order
+    sub = a[rows].contiguous()
+    c_ord = g.matmul(sub, b, "double", path=g.PATH_ORDERED)
+    rel = ((c[rows] - c_ord).abs() / c_ord).max().item()
+    assert rel < 1e-13, rel
+    c2 = g.matmul(a * 2.0, b, "double")
+    assert torch.equal(c2, c * 2.0)                    # power-of-two scaling commutes with rounding
+    del c2
+    perm = torch.randperm(n, device=a.device)
+    assert torch.equal(g.matmul(a[perm].contiguous(), b, "double"), c[perm])
+    assert torch.equal(g.matmul(a, b, "double"), c)
+
+
+# ---- C3: half (Multiply, Add) 32768^3 ----------------------------------------------------------------
+def test_half_32768_finite_inputs_sampled_rows_and_properties():
+    """Inputs = the generator's [1,10) values scaled by 2^-6 (exact in binary16, no subnormals), so that
+    sums over K = 32768 stay around 250 instead of overflowing: the contract (exact products, fp32
+    accumulation, ONE rounding to binary16) is then visible in every output."""
+    import torch
+    n = k = m = 32768
+    a = _device_fill("half", (n, k), 51)
+    b = _device_fill("half", (k, m), 52)
+    a.mul_(2.0 ** -6)
+    b.mul_(2.0 ** -6)
+    assert g.kernel_name(g.make_config("half"), n, k, m) == "mfma_f16"
+    c = g.matmul(a, b, "half")
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(c).all())
+    rows, cols = _sample(n, m)
+    ah, bh, ch = _host_slices(a, b, c, rows, cols)
+    wide = _oracle.naive("half", "Multiply", "Add", ah, bh, wide_half=True)
+    ulps = np.abs(ch.view(np.int16).astype(np.int32) - wide.view(np.int16).astype(np.int32))
+    assert ulps.max() <= 1, int(ulps.max())
+    exact = ah.astype(np.float64) @ bh.astype(np.float64)
+    rel = np.abs(ch.astype(np.float64) - exact) / exact
+    # half an ulp of binary16 + the fp32 accumulation error of a 32768-term chain of positive terms
+    assert rel.max() <= 2.0 ** -11 + 3e-5, float(rel.max())
+    c2 = g.matmul(a * 2.0, b, "half")
+    assert torch.equal(c2, c * 2.0)
+    del c2
+    perm = torch.randperm(n, device=a.device)
+    assert torch.equal(g.matmul(a[perm].contiguous(), b, "half"), c[perm])
+    assert torch.equal(g.matmul(a, b, "half"), c)
+
+
+def test_half_32768_reference_inputs_overflow_to_inf_everywhere():
+    """On BASELINE's own [1,10) data every sum passes 65504 long before K = 32768: the correctly
+    rounded binary16 result is +inf for every element -- which is also what the reference's
+    half-accumulating kernel produces -- and nothing may be NaN or negative."""
+    import torch
+    n = k = m = 32768
+    a = _device_fill("half", (n, k), 61)
+    b = _device_fill("half", (k, m), 62)
+    c = g.matmul(a, b, "half")
+    torch.cuda.synchronize()
+    assert bool((c == float("inf")).all())
+    # the k-ordered kernel (RunHardware hw_emu, half accumulation exactly like Naive) on a row sample
+    rows = [0, 255, 256, 16383, 32767]
+    c_ord = g.matmul(a[rows].contiguous(), b, "half", path=g.PATH_ORDERED)
+    assert bool((c_ord == float("inf")).all())
+
+
+# ---- fp32 with mixed signs ---------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(513, 528, 528), (300, 64, 272), (1024, 4104, 1024), (257, 8200, 520), (2048, 2048, 2048)],
+                         ids=lambda s: "x".join(map(str, s)))
+@pytest.mark.parametrize("transposed_a", [False, True], ids=["rowmajorA", "KxN_A"])
+def test_f32_mixed_sign_normwise_bound(shape, transposed_a):
+    """|c - exact| <= 1e-5 * (|A| . |B|) elementwise -- the form of BASELINE's 1e-5 bar that stays
+    meaningful under cancellation -- on uniform [-1, 1) operands."""
+    n, k, m = shape
+    if transposed_a and n % 4:
+        n += 4 - n % 4
+    rng = np.random.default_rng(n * 31 + k)
+    a = rng.uniform(-1, 1, size=(n, k)).astype(np.float32)
+    b = rng.uniform(-1, 1, size=(k, m)).astype(np.float32)
+    assert g.kernel_name(g.make_config("float", transposed_a=transposed_a), n, k, m).startswith("mfma_f32")
+    if transposed_a:
+        c, _ = g.matmul_capi(np.ascontiguousarray(a.T), b, transposed_a=True)
+    else:
+        c, _ = g.matmul_capi(a, b)
+    a64, b64 = a.astype(np.float64), b.astype(np.float64)
+    exact = a64 @ b64
+    bound = 1e-5 * (np.abs(a64) @ np.abs(b64))
+    err = np.abs(c - exact)
+    assert np.all(err <= bound), float((err / bound).max())
+    # sign structure: roughly half the outputs are negative, and every sign agrees wherever the exact
+    # value is not within the bound of zero
+    sure = np.abs(exact) > bound
+    assert np.array_equal(np.sign(c[sure]), np.sign(exact[sure]))
+    assert 0.3 < (c < 0).mean() < 0.7
+
+
+def test_f32_mixed_sign_full_size_sampled():
+    import torch
+    n = k = m = 16384
+    a = _device_fill("float", (n, k), 71)
+    b = _device_fill("float", (k, m), 72)
+    a.sub_(5.5)     # [-4.5, 4.5): one rounding, still exactly representable inputs for both sides
+    b.sub_(5.5)
+    c = g.matmul(a, b)
+    torch.cuda.synchronize()
+    rows, cols = _sample(n, m)
+    ah, bh, ch = _host_slices(a, b, c, rows, cols)
+    a64, b64 = ah.astype(np.float64), bh.astype(np.float64)
+    err = np.abs(ch - a64 @ b64)
+    bound = 1e-5 * (np.abs(a64) @ np.abs(b64))
+    assert np.all(err <= bound), float((err / bound).max())
+    c_neg = g.matmul(-a, b)
+    assert torch.equal(c_neg, -c)                      # negation is exact: (-A) B == -(A B) bit for bit
+
+
+# ---- other dtypes with signs / Max identity ------------------------------------------------------------
+@pytest.mark.parametrize("dtype", ["double", "half"])
+def test_f64_f16_mixed_sign(dtype):
+    n, k, m = 513, 1040, 528
+    rng = np.random.default_rng(17)
+    npdt = _oracle.NP_DTYPES[dtype]
+    a = rng.uniform(-1, 1, size=(n, k)).astype(npdt)
+    b = rng.uniform(-1, 1, size=(k, m)).astype(npdt)
+    assert g.kernel_name(g.make_config(dtype), n, k, m).startswith("mfma_")
+    c, _ = g.matmul_capi(a, b, dtype)
+    a64, b64 = a.astype(np.float64), b.astype(np.float64)
+    exact = a64 @ b64
+    absum = np.abs(a64) @ np.abs(b64)
+    err = np.abs(c.astype(np.float64) - exact)
+    if dtype == "double":
+        assert np.all(err <= 1e-13 * absum)
+    else:
+        # one rounding of the result to binary16 + fp32 accumulation noise relative to sum |a||b|
+        assert np.all(err <= 2.0 ** -11 * np.abs(exact) + 1e-6 * absum + 2.0 ** -25)
+
+
+@pytest.mark.parametrize("dtype", ["float", "double", "int", "half"])
+@pytest.mark.parametrize("path", [g.PATH_AUTO, g.PATH_ORDERED], ids=["auto", "ordered"])
+def test_max_reduce_over_all_negative_values_uses_lowest_identity(dtype, path):
+    """(Add, Max) / (Multiply, Max) where every mapped value is negative: the accumulator must be
+    seeded below them (identity() = lowest(), as Naive's seed behaves: DESIGN.md 3.3)."""
+    n, k, m = 130, 64, 96
+    a, b = _oracle.fill(dtype, n, k, m)
+    a = (-a).astype(a.dtype)
+    b = (-b).astype(b.dtype)
+    c, _ = g.matmul_capi(a, b, dtype, "Add", "Max", path=path)
+    want = _oracle.naive(dtype, "Add", "Max", a, b)
+    assert np.array_equal(c.view(np.uint8), want.view(np.uint8))
+    assert np.all(c.astype(np.float64) < 0)
+    # independent of the oracle: numpy in the native type (rounding is monotone, so max commutes with it)
+    assert np.array_equal(c, (a[:, :, None] + b[None]).max(axis=1))

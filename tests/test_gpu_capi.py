@@ -1,0 +1,238 @@
+"""GPU tests of the C-ABI's contract beyond the arithmetic: one half (x,+) contract for every
+shape, pointer alignment, argument checking of the torch binding, concurrent use from several
+host threads / streams, the multi-device row split, and the one-process-per-GPU bench launch."""
+import ctypes
+import json
+import os
+import subprocess
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+import _oracle
+import gemm_hls_amd as g
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("shape", [(129, 4104, 264), (65, 40, 8), (33, 4096, 12), (70, 2056, 20), (1, 2, 2)],
+                         ids=lambda s: "x".join(map(str, s)))
+@pytest.mark.parametrize("transposed_a", [False, True], ids=["rowmajorA", "KxN_A"])
+def test_half_auto_contract_does_not_depend_on_shape(shape, transposed_a):
+    """half (Multiply, Add) under MM_PATH_AUTO on shapes the matrix-core kernel
+    does not take (K % 16 != 0 or M % 8 != 0) keeps the f32-accumulate / round-once contract instead
+    of dropping to half accumulation (which would turn K = 4104 into inf where K = 4096 is finite)."""
+    n, k, m = shape
+    rng = np.random.default_rng(k * 7 + m)
+    a = rng.uniform(0.5, 2.0, size=(n, k)).astype(np.float16)
+    b = rng.uniform(0.5, 2.0, size=(k, m)).astype(np.float16)
+    assert g.kernel_name(g.make_config("half", transposed_a=transposed_a), n, k, m) == "ordered_wide_f16"
+    arg = np.ascontiguousarray(a.T) if transposed_a else a
+    c, _ = g.matmul_capi(arg, b, "half", transposed_a=transposed_a)
+    wide = _oracle.naive("half", "Multiply", "Add", a, b, wide_half=True)
+    assert np.all(np.isfinite(c.astype(np.float32)))
+    ulps = np.abs(c.view(np.int16).astype(np.int32) - wide.view(np.int16).astype(np.int32))
+    assert ulps.max() <= 1
+    if k >= 2056:  # the half-accumulating Naive is visibly different at this depth (stagnation)
+        narrow = _oracle.naive("half", "Multiply", "Add", a, b)
+        assert not np.array_equal(narrow, wide)
+
+
+def test_half_auto_is_continuous_across_the_k_multiple_of_16_boundary():
+    n, m = 64, 64
+    a, b = _oracle.fill("half", n, 4112, m)   # [1,10): sums pass 65504 near k ~ 2000
+    for k in (4096, 4104, 4112):
+        c, _ = g.matmul_capi(np.ascontiguousarray(a[:, :k]), np.ascontiguousarray(b[:k]), "half")
+        assert np.all(np.isinf(c.astype(np.float32))), k   # same (IEEE-correct) answer on both kernels
+    a2 = (a.astype(np.float32) / 64).astype(np.float16)
+    b2 = (b.astype(np.float32) / 64).astype(np.float16)
+    for k in (4096, 4104):
+        c, _ = g.matmul_capi(np.ascontiguousarray(a2[:, :k]), np.ascontiguousarray(b2[:k]), "half")
+        exact = a2[:, :k].astype(np.float64) @ b2[:k].astype(np.float64)
+        assert np.max(np.abs(c.astype(np.float64) - exact) / exact) <= 2.0 ** -11 * 1.02, k
+
+
+def test_unaligned_pointers_are_refused_by_the_fast_path_and_served_by_the_ordered_one():
+    import torch
+    dev = torch.device("cuda:0")
+    n = k = m = 256
+    base = torch.rand(n * k + 1, device=dev) + 1.0
+    a = base[1:].view(n, k)                       # contiguous, but 4 bytes past a 16-B boundary
+    b = torch.rand((k, m), device=dev) + 1.0
+    assert a.is_contiguous() and a.data_ptr() % 16 == 4
+    with pytest.raises(g.MMError, match="16-byte aligned"):
+        g.matmul(a, b)
+    c = g.matmul(a, b, path=g.PATH_ORDERED)
+    ref = a.double() @ b.double()
+    assert float(((c.double() - ref).abs() / ref).max()) < 1e-5
+    out = torch.empty(n * m + 1, device=dev)[1:].view(n, m)
+    with pytest.raises(g.MMError, match="16-byte aligned"):
+        g.matmul(b, b, out=out)
+
+
+def test_torch_binding_checks_out_and_operands():
+    import torch
+    dev = torch.device("cuda:0")
+    a = torch.ones((64, 32), device=dev)
+    b = torch.ones((32, 48), device=dev)
+    with pytest.raises(g.MMError, match="out must be"):
+        g.matmul(a, b, out=torch.empty((64, 47), device=dev))
+    with pytest.raises(g.MMError, match="out must be"):
+        g.matmul(a, b, out=torch.empty((64, 48), device=dev, dtype=torch.float64))
+    with pytest.raises(g.MMError, match="out must be"):
+        g.matmul(a, b, out=torch.empty((48, 64), device=dev).t())
+    with pytest.raises(g.MMError, match="inner dimensions"):
+        g.matmul(a, torch.ones((31, 48), device=dev))
+    with pytest.raises(g.MMError, match="contiguous"):
+        g.matmul(a.t(), torch.ones((64, 48), device=dev))
+    with pytest.raises(g.MMError, match="do not match"):
+        g.matmul(a.double(), b.double())
+    with pytest.raises(g.MMError, match="no CPU path"):
+        g.matmul(a.cpu(), b.cpu())
+
+
+def test_concurrent_launches_from_two_threads_on_two_streams():
+    """The header promises every entry point is callable concurrently.  Two host threads, each with
+    its own stream, interleave different configurations (MFMA fp32 incl. first-use LDS opt-in of
+    several geometries, VALU min-plus, int MFMA, timed blocking launches) on ONE device; results
+    must equal the serial ones bit for bit."""
+    import torch
+    dev = torch.device("cuda:0")
+    jobs = []
+    rng = np.random.default_rng(99)
+    for i, (dtype, ops, shape) in enumerate([
+            ("float", ("Multiply", "Add"), (1024, 1024, 1024)), ("float", ("Add", "Min"), (640, 256, 384)),
+            ("uint8_t", ("Multiply", "Add"), (512, 512, 512)), ("float", ("Multiply", "Add"), (300, 64, 272)),
+            ("double", ("Multiply", "Add"), (513, 528, 528)), ("half", ("Multiply", "Add"), (520, 528, 528)),
+            ("float", ("Multiply", "Add"), (2048, 512, 2048)), ("int", ("Multiply", "Add"), (257, 64, 96))]):
+        n, k, m = shape
+        tdt = g.torch_dtype(dtype)
+        if dtype in ("uint8_t", "int"):
+            a = torch.randint(1, 10, (n, k), device=dev).to(tdt)
+            b = torch.randint(1, 10, (k, m), device=dev).to(tdt)
+        else:
+            a = (torch.rand((n, k), device=dev) * 9 + 1).to(tdt)
+            b = (torch.rand((k, m), device=dev) * 9 + 1).to(tdt)
+        jobs.append((dtype, ops, a, b))
+    serial = [g.matmul(a, b, dtype, *ops) for (dtype, ops, a, b) in jobs]
+    torch.cuda.synchronize()
+    results = {}
+    errors = []
+
+    def worker(tid):
+        try:
+            stream = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(stream):
+                for rep in range(6):
+                    order = list(range(len(jobs)))
+                    if tid:
+                        order.reverse()
+                    for j in order:
+                        dtype, ops, a, b = jobs[j]
+                        out = g.matmul(a, b, dtype, *ops)
+                        results[(tid, rep, j)] = out
+                    # a blocking, timed C-ABI launch from this thread while the other one enqueues
+                    dtype, ops, a, b = jobs[3]
+                    cfg = g.make_config(dtype, *ops)
+                    t = ctypes.c_double(0)
+                    c = torch.empty((a.shape[0], b.shape[1]), dtype=a.dtype, device=dev)
+                    g._check(g.lib().mm_gemm_launch(0, ctypes.byref(cfg), a.data_ptr(), b.data_ptr(), c.data_ptr(),
+                                                    a.shape[0], a.shape[1], b.shape[1], ctypes.byref(t)))
+                    assert t.value > 0
+                    results[(tid, rep, "timed")] = c
+            stream.synchronize()
+        except Exception as exc:  # surfaced in the main thread
+            errors.append(exc)
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    torch.cuda.synchronize()
+    for (tid, rep, j), out in results.items():
+        want = serial[3] if j == "timed" else serial[j]
+        assert torch.equal(out, want), (tid, rep, j)
+
+
+def test_tuning_set_switches_geometry_in_process():
+    n = k = m = 512
+    a, b = _oracle.fill("float", n, k, m)
+    exact = a.astype(np.float64) @ b.astype(np.float64)
+    try:
+        for v in (3, 13, 14):
+            g.set_tuning("f32_variant", v)
+            assert g.get_tuning("f32_variant") == v
+            c, _ = g.matmul_capi(a, b)
+            assert np.max(np.abs(c - exact) / exact) < 1e-5
+        g.set_tuning("band_rows", 8)
+        c8, _ = g.matmul_capi(a, b)
+        g.set_tuning("band_rows", -1)
+        c4, _ = g.matmul_capi(a, b)
+        assert np.array_equal(c8, c4)           # rasterisation order never changes a result
+    finally:
+        g.set_tuning("f32_variant", -1)
+        g.set_tuning("band_rows", -1)
+
+
+def test_host_pointer_entry_with_explicit_config():
+    n, k, m = 130, 64, 96
+    a, b = _oracle.fill("int", n, k, m)
+    c = np.zeros((n, m), np.int32)
+    cfg = g.make_config("int")
+    g._check(g.lib().mm_gemm_host(ctypes.byref(cfg), a.ctypes.data, b.ctypes.data, c.ctypes.data, n, k, m))
+    assert np.array_equal(c, _oracle.naive("int", "Multiply", "Add", a, b))
+    # K x N A through the same entry (what an MM_TRANSPOSED_A build of the kernel shim forwards)
+    cfg_t = g.make_config("int", transposed_a=True)
+    at = np.ascontiguousarray(a.T)
+    c2 = np.zeros((n, m), np.int32)
+    g._check(g.lib().mm_gemm_host(ctypes.byref(cfg_t), at.ctypes.data, b.ctypes.data, c2.ctypes.data, n, k, m))
+    assert np.array_equal(c2, c)
+
+
+# ---- multi-GPU ------------------------------------------------------------------------------------
+def test_multi_device_ragged_split_is_bit_identical_to_one_device():
+    """Runs wherever >= 2 GPUs are visible (the driver's 8-GPU node; skipped on the 1-GPU box):
+    2 and ALL devices, N not divisible by the device count, against the one-device bits."""
+    import torch
+    have = torch.cuda.device_count()
+    if have < 2:
+        pytest.skip("needs at least 2 GPUs")
+    n, k, m = 2500 + 13, 1024, 1040
+    rng = np.random.default_rng(5)
+    a = rng.uniform(1, 10, size=(n, k)).astype(np.float32)
+    b = rng.uniform(1, 10, size=(k, m)).astype(np.float32)
+    c1, _ = g.matmul_host(a, b, devices=1)
+    for devices in sorted({2, have}):
+        cg, t = g.matmul_host(a, b, devices=devices)
+        assert np.array_equal(cg, c1), devices
+        assert t > 0
+    ai, bi = _oracle.fill("int", 1001, 64, 96)
+    want = _oracle.naive("int", "Multiply", "Add", ai, bi)
+    for devices in sorted({2, have}):
+        ci, _ = g.matmul_host(ai, bi, "int", devices=devices)
+        assert np.array_equal(ci, want)
+
+
+@pytest.mark.parametrize("scaling", ["strong", "weak"])
+def test_bench_two_ranks_on_one_device_smoke(scaling):
+    """The one-process-per-GPU launch of bench.py exactly as the driver issues it, with both ranks on
+    device 0 (MM_BENCH_DEVICE_MOD=1) and gloo as the control plane: checks the N > 1 control flow
+    (row_slab ownership, barrier, max over ranks, one JSON line from rank 0)."""
+    env = dict(os.environ, MM_BENCH_DEVICE_MOD="1", MM_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
+           "--warmup", "1", "--scaling", scaling, "--size", "2048", "--total-rows", "6000", "--no-extra"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["scaling"] == scaling
+    rows_total = 6000 if scaling == "strong" else 2 * 2048
+    assert out["config"]["rows_total"] == rows_total
+    assert abs(out["value"] - 1e-9 * 2.0 * rows_total * 2048 * 2048 * 2 / (out["ms_per_step"] * 2e-3)) / out["value"] < 1e-3

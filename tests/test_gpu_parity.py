@@ -24,13 +24,14 @@ F32_TOL = 1e-5
 SHAPES = [(513, 528, 528), (1, 16, 16), (37, 32, 48), (300, 64, 272), (129, 80, 260), (256, 8, 4), (1024, 1024, 1024)]
 
 
-def _f32_variants():
-    return range(g.lib().mm_f32_num_variants()) if hasattr(g.lib(), "mm_f32_num_variants") else range(8)
-
-
 @pytest.fixture(autouse=True)
-def _clear_variant(monkeypatch):
-    monkeypatch.delenv("MM_F32_VARIANT", raising=False)
+def _default_tuning():
+    """Every test starts and ends on the library's own geometry choice (knobs are process-wide)."""
+    for knob in ("f32_variant", "f64_variant", "f16_variant", "i8_variant", "band_rows"):
+        g.set_tuning(knob, -1)
+    yield
+    for knob in ("f32_variant", "f64_variant", "f16_variant", "i8_variant", "band_rows"):
+        g.set_tuning(knob, -1)
 
 
 @pytest.mark.parametrize("shape", SHAPES, ids=lambda s: "x".join(map(str, s)))
@@ -49,8 +50,8 @@ def test_f32_mfma_default_vs_blas_and_exact(shape):
 @pytest.mark.parametrize("variant", range(16))
 @pytest.mark.parametrize("shape", [(513, 528, 528), (300, 64, 272), (256, 8, 4), (37, 32, 48), (300, 8208, 272)],
                          ids=lambda s: "x".join(map(str, s)))
-def test_f32_mfma_every_variant(variant, shape, monkeypatch):
-    monkeypatch.setenv("MM_F32_VARIANT", str(variant))
+def test_f32_mfma_every_variant(variant, shape):
+    g.set_tuning("f32_variant", variant)
     n, k, m = shape
     a, b = _oracle.fill("float", n, k, m)
     c, _ = g.matmul_capi(a, b)

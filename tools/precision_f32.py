@@ -34,7 +34,7 @@ def main():
     del b64
     c = torch.empty((n, n), dtype=torch.float32, device=dev)
     for v in [int(x) for x in args.variants.split(",")]:
-        os.environ["MM_F32_VARIANT"] = str(v)
+        g.set_tuning("f32_variant", v)
         g.matmul(a, b, out=c)
         torch.cuda.synchronize()
         t0 = time.perf_counter()

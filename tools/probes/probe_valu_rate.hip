@@ -1,18 +1,33 @@
 // Hardware probe: sustained issue rate of the VALU instructions a min-plus inner loop can be built
-// from (wave64 on gfx950).  Every variant runs 16 independent accumulators per lane so that only
-// issue rate matters.  Output: T lane-instructions per second and cycles per wave-instruction.
+// from (wave64 on gfx950) -- the ceiling the valu_tile kernel is priced against.
+//
+// Round-1's version assumed a 2.4 GHz clock when converting wall time into cycles; under a pure
+// VALU load the chip does not hold 2.4 GHz, so its "cycles per instruction" were too high and the
+// kernel appeared to beat its own ceiling.  This version measures CYCLES
+// directly: every wave brackets its instruction stream with s_memtime (tick = shader cycle,
+// MI355X_MICROARCH.md constants table), exactly one workgroup of WPS*4 waves runs per CU (WPS waves
+// per SIMD, all co-resident for the whole measurement), and
+//     cycles per wave-instruction per SIMD = mean wave elapsed / (instructions per wave * WPS).
+// The delivered clock = (cycles the slowest wave counted) / (wall time of the launch) is reported
+// next to it, so a ceiling in op/s can be stated at the clock the chip actually sustains.
+// 16 independent accumulators per lane: dependency latency never limits issue.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
+#include <algorithm>
 typedef float f2 __attribute__((ext_vector_type(2)));
-#define ITERS 4096
+#define ITERS 2048
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
+
 template <int MODE>
-__global__ __launch_bounds__(256) void k(float *out, float x, float y) {
+__global__ __launch_bounds__(1024) void k(float *out, unsigned long long *cyc, float x, float y) {
   float a[16];
   f2 p[8];
   for (int i = 0; i < 16; ++i) a[i] = threadIdx.x + i;
   for (int i = 0; i < 8; ++i) p[i] = f2{(float)threadIdx.x, (float)i};
   const f2 xy = {x, y};
+  __syncthreads();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
   for (int it = 0; it < ITERS; ++it) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -22,35 +37,81 @@ __global__ __launch_bounds__(256) void k(float *out, float x, float y) {
       if (MODE == 3) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(a[i]) : "v"(x), "v"(y));
       if (MODE == 4) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p[i & 7]) : "v"(xy));
       if (MODE == 5) asm volatile("v_pk_fma_f32 %0, %1, %1, %0" : "+v"(p[i & 7]) : "v"(xy));
-      if (MODE == 6) asm volatile("v_min3_f32 %0, %0, %1, %1" : "+v"(a[i]) : "v"(x));
+      if (MODE == 6) asm volatile("v_max_f32 %0, %0, %1" : "+v"(a[i]) : "v"(x));
       if (MODE == 7) asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[i]) : "v"(x));
+      if (MODE == 8) asm volatile("v_min_u32 %0, %0, %1" : "+v"(a[i]) : "v"(x));
+      // the float min-plus inner loop as valu_tile compiles it: per accumulator and pair of k-steps
+      // two adds into temporaries and ONE v_min3 (acc, s0, s1): 3 instructions per 4 operations
+      if (MODE == 9) {
+        float s0, s1;
+        asm volatile("v_add_f32 %0, %1, %2" : "=v"(s0) : "v"(x), "v"(a[(i + 1) & 15]));
+        asm volatile("v_add_f32 %0, %1, %2" : "=v"(s1) : "v"(y), "v"(a[(i + 2) & 15]));
+        asm volatile("v_min3_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(s0), "v"(s1));
+      }
+      // the same with a plain 2-source min twice (what it would be without v_min3)
+      if (MODE == 10) {
+        float s0, s1;
+        asm volatile("v_add_f32 %0, %1, %2" : "=v"(s0) : "v"(x), "v"(a[(i + 1) & 15]));
+        asm volatile("v_add_f32 %0, %1, %2" : "=v"(s1) : "v"(y), "v"(a[(i + 2) & 15]));
+        asm volatile("v_min_f32 %0, %0, %1" : "+v"(a[i]) : "v"(s0));
+        asm volatile("v_min_f32 %0, %0, %1" : "+v"(a[i]) : "v"(s1));
+      }
     }
   }
+  asm volatile("s_nop 0" ::: "memory");
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
   float s = 0;
   for (int i = 0; i < 16; ++i) s += a[i];
   for (int i = 0; i < 8; ++i) s += p[i][0] + p[i][1];
-  out[blockIdx.x * 256 + threadIdx.x] = s;
+  out[blockIdx.x * 1024 + threadIdx.x] = s;
+  if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 16 + (threadIdx.x >> 6)] = t1 - t0;
 }
+
 template <int MODE>
-void run(const char *name, float *d) {
-  const int blocks = 256 * 8;
+int run(const char *name, int insts_per_slot, double ops_per_slot, int wps, float *d, unsigned long long *dc) {
+  const int blocks = 256, threads = wps * 256;  // one workgroup per CU, wps waves on each SIMD
   hipEvent_t e0, e1;
-  hipEventCreate(&e0); hipEventCreate(&e1);
-  k<MODE><<<blocks, 256>>>(d, 1.0f, 2.0f);
-  hipEventRecord(e0);
-  k<MODE><<<blocks, 256>>>(d, 1.0f, 2.0f);
-  hipEventRecord(e1);
-  hipEventSynchronize(e1);
-  float ms; hipEventElapsedTime(&ms, e0, e1);
-  const double lane_instr = (double)blocks * 256 * ITERS * 16;
-  const double rate = lane_instr / (ms * 1e-3);
-  printf("%-28s %7.2f T lane-instr/s   %5.2f cycles per wave-instr per SIMD (at 2.4 GHz)\n", name, rate / 1e12,
-         1024 * 2.4e9 / (rate / 64));
+  CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+  k<MODE><<<blocks, threads>>>(d, dc, 1.0f, 2.0f);
+  CHECK(hipDeviceSynchronize());
+  CHECK(hipEventRecord(e0));
+  k<MODE><<<blocks, threads>>>(d, dc, 1.0f, 2.0f);
+  CHECK(hipEventRecord(e1));
+  CHECK(hipEventSynchronize(e1));
+  float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+  std::vector<unsigned long long> c(blocks * 16);
+  CHECK(hipMemcpy(c.data(), dc, c.size() * 8, hipMemcpyDeviceToHost));
+  double sum = 0; unsigned long long mx = 0; int cnt = 0;
+  for (int b = 0; b < blocks; ++b) for (int w = 0; w < wps * 4; ++w) { sum += c[b * 16 + w]; mx = std::max(mx, c[b * 16 + w]); ++cnt; }
+  const double per_wave = sum / cnt;
+  const double inst = (double)ITERS * 16 * insts_per_slot;
+  const double cyc_per_inst = per_wave / (inst * wps);
+  const double clock_ghz = (double)mx / (ms * 1e6);   // slowest wave's cycles over the launch's wall time (lower bound)
+  const double ops_per_cyc_simd = 64.0 * ops_per_slot / (cyc_per_inst * insts_per_slot);
+  printf("%-34s wps %d  %6.3f cyc/wave-instr/SIMD  clock >= %5.3f GHz  %7.2f T lane-instr/s wall", name, wps, cyc_per_inst,
+         clock_ghz, 256.0 * threads * inst / (ms * 1e-3) / 1e12);
+  if (ops_per_slot > 0)
+    printf("  | %6.2f op/clk/SIMD -> %6.1f TOp/s at this clock, %6.1f at 2.4 GHz", ops_per_cyc_simd,
+           ops_per_cyc_simd * 1024 * clock_ghz / 1e3, ops_per_cyc_simd * 1024 * 2.4 / 1e3);
+  printf("\n");
+  return 0;
 }
+
 int main() {
-  float *d; hipMalloc(&d, 256 * 8 * 256 * 4);
-  run<0>("v_add_f32 (2 src)", d); run<1>("v_min_f32 (2 src)", d); run<2>("v_min3_f32 (3 distinct src)", d);
-  run<6>("v_min3_f32 (2 distinct src)", d); run<3>("v_fma_f32", d); run<4>("v_pk_add_f32", d);
-  run<5>("v_pk_fma_f32", d); run<7>("v_add_u32", d);
+  float *d; unsigned long long *dc;
+  CHECK(hipMalloc(&d, 256 * 1024 * 4)); CHECK(hipMalloc(&dc, 256 * 16 * 8));
+  for (int wps : {1, 2, 4}) {
+    run<0>("v_add_f32 (2 src)", 1, 0, wps, d, dc);
+    run<1>("v_min_f32 (2 src)", 1, 0, wps, d, dc);
+    run<6>("v_max_f32 (2 src)", 1, 0, wps, d, dc);
+    run<2>("v_min3_f32 (3 src)", 1, 0, wps, d, dc);
+    run<3>("v_fma_f32", 1, 0, wps, d, dc);
+    run<4>("v_pk_add_f32", 1, 0, wps, d, dc);
+    run<5>("v_pk_fma_f32", 1, 0, wps, d, dc);
+    run<7>("v_add_u32", 1, 0, wps, d, dc);
+    run<8>("v_min_u32", 1, 0, wps, d, dc);
+    run<9>("min-plus mix: 2 v_add + 1 v_min3", 3, 4, wps, d, dc);
+    run<10>("min-plus mix: 2 v_add + 2 v_min", 4, 4, wps, d, dc);
+  }
   return 0;
 }

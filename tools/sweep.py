@@ -47,7 +47,7 @@ def main():
     if args.what == "f32":
         variants = [int(v) for v in args.variants.split(",")] if args.variants else list(range(8))
         for v in variants:
-            os.environ["MM_F32_VARIANT"] = str(v)
+            g.set_tuning("f32_variant", v)
             for s in sizes:
                 name = g.kernel_name(g.make_config("float"), s, s, s)
                 med, best = time_config("float", "Multiply", "Add", s, s, s, args.reps)
