@@ -20,6 +20,7 @@
 //     of the 256-B bank row: each half-wave then reads 256 distinct bytes.
 // Edges: N arbitrary, K % 16 == 0, M % 8 == 0 (reference contract for half: K % 32, M % 32).
 #include <cstdlib>
+#include <type_traits>
 
 #include "mm_common.h"
 
@@ -274,6 +275,197 @@ __global__ __launch_bounds__(G::THREADS) void mfma_f16_kernel(const _Float16 *__
   }
 }
 
+
+// =================================================================================================
+// Ping-pong kernel (round 2): the same 256 x 256 resident tile, rescheduled so that the matrix pipe
+// of every SIMD is fed by ONE of its two waves at a time while the other one does all of its memory
+// work.  Why: in the kernel above both waves of a SIMD run the same phase at the same time; each
+// LDS-DMA instruction blocks its wave's in-order issue for 60-190 cycles (MI355X_MICROARCH.md
+// constants: "LDS-DMA piece issue cost"), so right after every slab barrier all 8 waves sit in their
+// DMA issue and the matrix pipes idle (ablation: no refill = +31 %).  Here
+//   * k-slabs are 32 deep (2 MFMA k-steps), 4-slab LDS ring (4 x 32 KiB), 3 slabs in flight;
+//   * waves 0-3 (one per SIMD) and waves 4-7 (their SIMD partners) run the same code shifted by one
+//     barrier: while group X executes its 16 MFMAs of slab u ("compute segment", priority 1),
+//     group Y reads its fragments of its next slab from LDS and issues its 4 DMA pieces of a slab
+//     three ahead ("load segment"); one s_barrier per segment keeps the two groups in antiphase;
+//   * 8 waves as 2 x 4, 128 x 64 per wave = 4 x 2 accumulators: per slab 8 ds_read_b128 (A) + 8
+//     ds_read_b64_tr_b16 (B) for 16 MFMAs, fragments single-buffered (load and compute segments of
+//     one wave never overlap -- the overlap comes from the partner wave);
+//   * DMA sources are (uniform SGPR base) + (32-bit per-lane offset): the per-lane part never
+//     changes, the base advances by one slab per segment with scalar adds: no vector address math
+//     in the loop.
+// LDS-DMA hand-over rules (cdna_hip_programming.md, 8-phase template): a slab is read one segment
+// AFTER the counted vmcnt + barrier that retires it; a buffer is refilled only after a barrier that
+// every reader passed with lgkmcnt(0).
+//   A slab image [256 rows][32 k]: 64-B rows, 16-B chunk index XORed with (row>>2)&3 (a
+//   ds_read_b128 lane group = 16 rows x 16 B must cover all 16 slots of the 256-B bank row);
+//   B slab image [32 k][256 cols]: as above (chunk index ^ (k&3)<<2).
+// Requirements: K % 32 == 0 (the reference's own contract for half: 64-byte bus = 32 elements,
+// host/RunHardware.cpp:50-55), M % 8 == 0, row-major A.  Other shapes: the kernel above.
+struct GeoPP {
+  static constexpr int BM = 256, BN = 256, BK = 32, NS = 4, NW = 8, THREADS = 512;
+  static constexpr int TM = 4, TN = 2;  // 128 x 64 per wave
+  static constexpr int A_BYTES = BM * BK * 2, B_BYTES = BK * BN * 2, STAGE_BYTES = A_BYTES + B_BYTES;
+  static constexpr int LDS_BYTES = NS * STAGE_BYTES;  // 128 KiB; the epilogue needs 8 x 128 x 128 B = 128 KiB
+  static constexpr int BROW = BN * 2;
+};
+
+// one LDS-DMA piece: 64 lanes x 16 B from (uniform base + per-lane 32-bit offset) to LDS at m0
+#define MM_DMA_PIECE(vo, sb, la) "s_mov_b32 m0, " la "\n\ts_nop 0\n\tglobal_load_lds_dwordx4 " vo ", " sb "\n\t"
+
+template <int VAR>  // bit 0: s_setprio around the MFMA segment; bit 1: lock-step ablation (no antiphase)
+__global__ __launch_bounds__(GeoPP::THREADS) void mfma_f16_pp_kernel(const _Float16 *__restrict__ A,
+                                                                       const _Float16 *__restrict__ B,
+                                                                       _Float16 *__restrict__ C, unsigned N, unsigned K,
+                                                                       unsigned M, unsigned tiles_n, unsigned tiles_m,
+                                                                       unsigned kBand) {
+  using G = GeoPP;
+  constexpr int TM = G::TM, TN = G::TN;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const unsigned lane = threadIdx.x & 63u;
+  const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const unsigned group = wave >> 2;                 // waves w and w+4 share a SIMD
+  const unsigned wq = wave & 3u;
+  const unsigned wm = wq >> 1, wn = (wq & 1u) * 2 + group;  // 2 x 4 wave grid; partners sit side by side
+  const unsigned lo = lane & 31u, hi = lane >> 5;
+
+  const unsigned nwg = tiles_n * tiles_m;
+  const unsigned lin = xcd_remap(blockIdx.x, nwg);
+  const unsigned band = lin / (kBand * tiles_m), within = lin % (kBand * tiles_m);
+  const unsigned rows_in_band = min(kBand, tiles_n - band * kBand);
+  const unsigned row0 = (band * kBand + within % rows_in_band) * G::BM, col0 = (within / rows_in_band) * G::BN;
+
+  // ---- DMA: per-lane offsets (constant) and uniform bases (advance with k) ----------------------
+  unsigned voff_a[2], voff_b[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const unsigned piece = wave + 8 * i;               // 16 A pieces of 16 rows x 64 B
+    const unsigned row = piece * 16 + lane / 4, pc = lane % 4;
+    const unsigned chunk = pc ^ ((row >> 2) & 3u);
+    voff_a[i] = (min(row0 + row, N - 1) - row0) * K * 2 + chunk * 16;
+    const unsigned kr = piece * 2 + lane / 32, pb = lane % 32;  // 16 B pieces of 2 k-rows x 512 B
+    const unsigned lc = pb ^ ((kr & 3u) << 2);
+    voff_b[i] = kr * M * 2 + (min(col0 + lc * 8, M - 8) - col0) * 2;
+  }
+  const char *a_base = (const char *)A + (size_t)row0 * K * 2;
+  const char *b_base = (const char *)B + (size_t)col0 * 2;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
+  const unsigned U = K / G::BK;
+  auto issue = [&](unsigned slab, unsigned buf) {
+    const unsigned sl = min(slab, U - 1);               // past the end: harmless re-fetch into a dead buffer
+    const char *ap = a_base + (size_t)sl * (G::BK * 2);
+    const char *bp = b_base + (size_t)sl * G::BK * M * 2;
+    const unsigned la0 = lds0 + buf * G::STAGE_BYTES + wave * 1024, la1 = la0 + 8 * 1024;
+    const unsigned lb0 = la0 + G::A_BYTES, lb1 = lb0 + 8 * 1024;
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\t" MM_DMA_PIECE("%1", "%5", "%7") MM_DMA_PIECE("%2", "%5", "%8")
+                     MM_DMA_PIECE("%3", "%6", "%9") MM_DMA_PIECE("%4", "%6", "%10") "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff_a[0]), "v"(voff_a[1]), "v"(voff_b[0]), "v"(voff_b[1]), "s"(ap), "s"(bp), "s"(la0), "s"(la1),
+                   "s"(lb0), "s"(lb1)
+                 : "memory");
+  };
+
+  // ---- fragment addresses (per lane, constant) ---------------------------------------------------
+  // A: row = wm*128 + mi*32 + lo ; chunk(ks) = (2*ks + hi) ^ ((lo>>2)&3) = (2*ks) ^ c, c = hi ^ ((lo>>2)&3)
+  const unsigned ca = hi ^ ((lo >> 2) & 3u);
+  const unsigned a_row_byte = (wm * 128 + lo) * (G::BK * 2);
+  const unsigned a_off[2] = {a_row_byte + ca * 16, a_row_byte + (ca ^ 2u) * 16};
+  // B (transpose read): x = lane&15 -> k row r = x>>2 of a 4-row block, 8-B piece (x&3) of the block's 32 B
+  //   k = ks*16 + 8*hi + 4*h + r ; logical chunk = wn*8 + ni*4 + 2*gq + ((x&3)>>1) ; physical = logical ^ (r<<2)
+  const unsigned x = lane & 15u, gq = (lane >> 4) & 1u, r = x >> 2;
+  unsigned b_off[TN];
+#pragma unroll
+  for (int ni = 0; ni < TN; ++ni) {
+    const unsigned logical = wn * 8 + ni * 4 + 2 * gq + ((x & 3u) >> 1);
+    b_off[ni] = G::A_BYTES + (8 * hi + r) * G::BROW + (logical ^ (r << 2)) * 16 + (x & 1u) * 8;
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni) acc[mi][ni] = (f32x16)0.0f;
+
+  auto sync = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // one slab: load segment | barrier | compute segment | barrier
+  auto phase = [&](auto bufc, unsigned u) {
+    constexpr int BUF = decltype(bufc)::value;
+    const char *base = smem + BUF * G::STAGE_BYTES;
+    h8 af[TM][2], bf[TN][2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int ni = 0; ni < TN; ++ni) {
+        const char *p = base + b_off[ni] + ks * 16 * G::BROW;
+        const s4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s4 __attribute__((address_space(3))) *)(lptr_t)p);
+        const s4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s4 __attribute__((address_space(3))) *)(lptr_t)(p + 4 * G::BROW));
+        bf[ni][ks] = join(v0, v1);
+      }
+#pragma unroll
+      for (int mi = 0; mi < TM; ++mi) af[mi][ks] = *(const h8 *)(base + a_off[ks] + mi * 32 * (G::BK * 2));
+    }
+    issue(u + 3, (BUF + 3) & 3);
+    asm volatile("s_waitcnt vmcnt(8)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");  // own pieces of slab u+1 landed; fragments in registers
+    sync();
+    if (VAR & 1) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mi][ks], bf[ni][ks], acc[mi][ni], 0, 0, 0);
+    if (VAR & 1) __builtin_amdgcn_s_setprio(0);
+    sync();
+  };
+
+  // ---- prologue: 3 slabs in flight, slab 0 published -------------------------------------------------
+  issue(0, 0);
+  issue(1, 1);
+  issue(2, 2);
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  sync();
+  const bool shifted = !(VAR & 2) && group == 1;
+  if (shifted) sync();                                   // group 1 runs one segment behind group 0
+  for (unsigned u = 0; u < U; u += 4) {
+    phase(std::integral_constant<int, 0>{}, u);
+    if (u + 1 < U) phase(std::integral_constant<int, 1>{}, u + 1);
+    if (u + 2 < U) phase(std::integral_constant<int, 2>{}, u + 2);
+    if (u + 3 < U) phase(std::integral_constant<int, 3>{}, u + 3);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // trailing (dead) refills must have landed before LDS is reused
+  if (!shifted && !(VAR & 2)) sync();                    // group 0 waits for group 1's last segment
+  sync();
+
+  // ---- epilogue: one rounding f32 -> binary16, staged through this wave's 16 KiB slice of the ring
+  {
+    char *slice = smem + wave * (128 * 128);
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+          const unsigned row = mi * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * hi;
+          *(_Float16 *)(slice + row * 128 + (ni * 32 + lo) * 2) = (_Float16)acc[mi][ni][rr];
+        }
+    using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+#pragma unroll
+    for (int it = 0; it < 128 * 8 / 64; ++it) {
+      const unsigned c = it * 64 + lane, row = c / 8, ch = c % 8;
+      const u32x4 v = *(const u32x4 *)(slice + row * 128 + ch * 16);
+      const unsigned grow = row0 + wm * 128 + row, gcol = col0 + wn * 64 + ch * 8;
+      if (grow < N && gcol < M) *(u32x4 *)(C + (size_t)grow * M + gcol) = v;
+    }
+  }
+}
+#undef MM_DMA_PIECE
+
 }  // namespace
 
 bool mfma_f16_serves(const Problem &p) {
@@ -291,6 +483,21 @@ static int launch_h(hipStream_t s, const Problem &p) {
   return (int)hipGetLastError();
 }
 
+bool mfma_f16_pp_serves(const Problem &p) {
+  return !p.a_transposed && p.k % 32 == 0 && p.k >= 128 && p.m % 8 == 0 && p.m >= 8 && p.n >= 1;
+}
+
+template <int VAR>
+static int launch_pp(hipStream_t s, const Problem &p) {
+  using G = GeoPP;
+  const unsigned tiles_n = (p.n + G::BM - 1) / G::BM, tiles_m = (p.m + G::BN - 1) / G::BN;
+  static unsigned long long configured = 0;
+  if (int e = ensure_dynamic_lds((const void *)mfma_f16_pp_kernel<VAR>, G::LDS_BYTES, configured)) return e;
+  hipLaunchKernelGGL((mfma_f16_pp_kernel<VAR>), dim3(tiles_n * tiles_m), dim3(G::THREADS), G::LDS_BYTES, s,
+                     (const _Float16 *)p.a, (const _Float16 *)p.b, (_Float16 *)p.c, p.n, p.k, p.m, tiles_n, tiles_m, band_rows());
+  return (int)hipGetLastError();
+}
+
 int mfma_f16_tile(const Problem &p) {  // 0: 256x256, 4: 128x256
   static const TileCandidate cands[] = {{0, 256, 256, 1, 1.00}, {4, 128, 256, 1, 0.80}};
   return p.a_transposed ? 0 : pick_tile(cands, 2, p.n, p.m);
@@ -300,6 +507,14 @@ int launch_mfma_f16(hipStream_t s, const Problem &p) {
   if (!mfma_f16_serves(p)) return kErrNotSupported;
   if (p.a_transposed) return launch_h<GeoH, true>(s, p);
   const int v = tuning(TUNE_F16_VARIANT);  // tuning hook
+  if (v >= 10 && v <= 13 && mfma_f16_pp_serves(p)) {
+    switch (v) {
+      case 10: return launch_pp<0>(s, p);
+      case 11: return launch_pp<1>(s, p);
+      case 12: return launch_pp<2>(s, p);
+      default: return launch_pp<3>(s, p);
+    }
+  }
   if (v == 1) return launch_h<GeoH4>(s, p);
   if (v == 2) return launch_h<GeoH32x4>(s, p);
   if (v == 3) return launch_h<GeoH32x3>(s, p);

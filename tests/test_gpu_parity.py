@@ -122,6 +122,27 @@ def test_f16_mfma_wide_accumulate_contract(shape):
     assert rel.max() <= 2.0 ** -11 * 1.01      # half an ulp of binary16 relative to the exact value (+f32 noise)
 
 
+@pytest.mark.parametrize("variant", [10, 11, 12, 13, 0, 1, 4])
+@pytest.mark.parametrize("shape", [(513, 544, 528), (300, 128, 272), (257, 1056, 520), (1024, 4096, 1024), (129, 160, 264),
+                                   (770, 2048, 1288)], ids=lambda s: "x".join(map(str, s)))
+def test_f16_mfma_every_variant(variant, shape):
+    """Every schedule of the half kernel (10-13: ping-pong with / without priority and the lock-step
+    ablation; 0, 1, 4: the one-slab-per-barrier geometries) against the wide-accumulate oracle, and
+    all of them against each other: same products, fp32 accumulation in k order per 16-deep MFMA."""
+    n, k, m = shape
+    rng = np.random.default_rng(n + k)
+    a = rng.uniform(-2, 2, size=(n, k)).astype(np.float16)     # mixed signs: cancellation shows layout bugs
+    b = rng.uniform(-2, 2, size=(k, m)).astype(np.float16)
+    g.set_tuning("f16_variant", variant)
+    c, _ = g.matmul_capi(a, b, "half")
+    g.set_tuning("f16_variant", -1)
+    a64, b64 = a.astype(np.float64), b.astype(np.float64)
+    exact = a64 @ b64
+    err = np.abs(c.astype(np.float64) - exact)
+    bound = 2.0 ** -11 * np.abs(exact) + 5e-7 * (np.abs(a64) @ np.abs(b64)) + 2.0 ** -25
+    assert np.all(err <= bound), (variant, float((err / bound).max()), np.unravel_index(np.argmax(err / bound), err.shape))
+
+
 @pytest.mark.parametrize("dtype,shape", [("double", (516, 528, 528)), ("double", (2, 8, 2)), ("double", (300, 64, 272)),
                                          ("half", (520, 528, 528)), ("half", (8, 16, 8)), ("half", (304, 64, 272)),
                                          ("uint8_t", (528, 544, 528)), ("int8_t", (16, 32, 16)), ("uint8_t", (304, 4128, 272))],

@@ -20,8 +20,9 @@ PASSES = [
     ["TCC_HIT_sum", "TCC_MISS_sum"],
     ["SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_VMEM", "SQ_INSTS_VALU", "SQ_INSTS_LDS"],
 ]
-KERNEL = {"f32": "mfma_f32_kernel", "f64": "mfma_f64_kernel", "f16": "mfma_f16_kernel", "minplus": "valu_tile_kernel",
-          "uint8": "mfma_i8_kernel"}
+KERNEL = {"f32": "mfma_f32_kernel", "f64": "mfma_f64_kernel", "f16": "mfma_f16_", "minplus": "valu_tile_kernel",
+          "uint8": "mfma_i8_"}
+VARIANT = None  # --variant: pins the family's tuning knob (sweep.py --variants) for every pass
 
 
 def run_pass(counters, what, size, workdir, idx):
@@ -30,7 +31,9 @@ def run_pass(counters, what, size, workdir, idx):
     os.makedirs(d, exist_ok=True)
     cmd = ["rocprofv3", "--pmc", *counters, "--kernel-trace", "-d", d, "-o", "pmc", "--output-format", "csv", "--",
            sys.executable, os.path.join(ROOT, "tools", "sweep.py"), what, "--sizes", str(size), "--reps", "3"]
-    if what == "f32" and os.environ.get("MM_F32_VARIANT"):
+    if VARIANT is not None:
+        cmd += ["--variants", str(VARIANT)]
+    elif what == "f32" and os.environ.get("MM_F32_VARIANT"):
         cmd += ["--variants", os.environ["MM_F32_VARIANT"]]
     elif what == "f32":
         cmd += ["--variants", "8"]
@@ -57,9 +60,12 @@ def main():
     ap.add_argument("what", choices=list(KERNEL))
     ap.add_argument("--size", type=int, default=16384)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--variant", type=int, default=None)
     ap.add_argument("--workdir", default=os.path.join(ROOT, "gpurun_out", "pmc_mfma"))
     args = ap.parse_args()
-    res = {"kernel": KERNEL[args.what], "size": args.size, "passes": []}
+    global VARIANT
+    VARIANT = args.variant
+    res = {"kernel": KERNEL[args.what], "variant": args.variant, "size": args.size, "passes": []}
     flat = {}
     for i, p in enumerate(PASSES):
         r = run_pass(p, args.what, args.size, os.path.join(args.workdir, args.what), i)

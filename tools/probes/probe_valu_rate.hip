@@ -7,7 +7,8 @@
 // directly: every wave brackets its instruction stream with s_memtime (tick = shader cycle,
 // MI355X_MICROARCH.md constants table), exactly one workgroup of WPS*4 waves runs per CU (WPS waves
 // per SIMD, all co-resident for the whole measurement), and
-//     cycles per wave-instruction per SIMD = mean wave elapsed / (instructions per wave * WPS).
+//     cycles per wave-instruction per SIMD = slowest wave's elapsed / (instructions per wave * WPS)
+// (slowest, not mean: the SIMD arbiter favours the older wave, so co-resident waves finish apart).
 // The delivered clock = (cycles the slowest wave counted) / (wall time of the launch) is reported
 // next to it, so a ceiling in op/s can be stated at the clock the chip actually sustains.
 // 16 independent accumulators per lane: dependency latency never limits issue.
@@ -16,7 +17,7 @@
 #include <vector>
 #include <algorithm>
 typedef float f2 __attribute__((ext_vector_type(2)));
-#define ITERS 2048
+#define ITERS 32768
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 
 template <int MODE>
@@ -81,8 +82,14 @@ int run(const char *name, int insts_per_slot, double ops_per_slot, int wps, floa
   float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
   std::vector<unsigned long long> c(blocks * 16);
   CHECK(hipMemcpy(c.data(), dc, c.size() * 8, hipMemcpyDeviceToHost));
+  // the SIMD's arbiter is not fair (priority, then age): co-resident waves finish at different times,
+  // so the SIMD's busy time is the SLOWEST wave's elapsed, not the mean (a mean would under-count)
   double sum = 0; unsigned long long mx = 0; int cnt = 0;
-  for (int b = 0; b < blocks; ++b) for (int w = 0; w < wps * 4; ++w) { sum += c[b * 16 + w]; mx = std::max(mx, c[b * 16 + w]); ++cnt; }
+  for (int b = 0; b < blocks; ++b) {
+    unsigned long long bm = 0;
+    for (int w = 0; w < wps * 4; ++w) bm = std::max(bm, c[b * 16 + w]);
+    sum += bm; mx = std::max(mx, bm); ++cnt;
+  }
   const double per_wave = sum / cnt;
   const double inst = (double)ITERS * 16 * insts_per_slot;
   const double cyc_per_inst = per_wave / (inst * wps);
@@ -100,7 +107,7 @@ int run(const char *name, int insts_per_slot, double ops_per_slot, int wps, floa
 int main() {
   float *d; unsigned long long *dc;
   CHECK(hipMalloc(&d, 256 * 1024 * 4)); CHECK(hipMalloc(&dc, 256 * 16 * 8));
-  for (int wps : {1, 2, 4}) {
+  for (int wps : {1, 2, 4}) {  // 4 waves per SIMD = 1024 threads, the largest single workgroup
     run<0>("v_add_f32 (2 src)", 1, 0, wps, d, dc);
     run<1>("v_min_f32 (2 src)", 1, 0, wps, d, dc);
     run<6>("v_max_f32 (2 src)", 1, 0, wps, d, dc);

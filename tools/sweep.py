@@ -57,14 +57,22 @@ def main():
     else:
         table = {"f64": ("double", "Multiply", "Add"), "f16": ("half", "Multiply", "Add"),
                  "minplus": ("float", "Add", "Min"), "uint8": ("uint8_t", "Multiply", "Add")}
+        knob = {"f64": "f64_variant", "f16": "f16_variant", "uint8": "i8_variant"}
         for key in ([args.what] if args.what != "all" else list(table)):
             dtype, mp, rd = table[key]
+            variants = [int(v) for v in args.variants.split(",")] if (args.variants and key in knob) else [-1]
             for s in sizes:
-                name = g.kernel_name(g.make_config(dtype, mp, rd), s, s, s)
-                med, best = time_config(dtype, mp, rd, s, s, s, args.reps)
-                tf = 2.0 * s ** 3 / med / 1e12
-                print(f"{key} {name:30s} {s:6d}^3  med {med*1e3:9.3f} ms  {tf:8.2f} TOp/s  best {2.0*s**3/best/1e12:8.2f}",
-                      flush=True)
+                # variants interleaved per size, in one process: within-probe A/B (guide rule 24)
+                for v in variants:
+                    if key in knob:
+                        g.set_tuning(knob[key], v)
+                    name = g.kernel_name(g.make_config(dtype, mp, rd), s, s, s)
+                    med, best = time_config(dtype, mp, rd, s, s, s, args.reps)
+                    tf = 2.0 * s ** 3 / med / 1e12
+                    print(f"{key} v{v:<3d} {name:24s} {s:6d}^3  med {med*1e3:9.3f} ms  {tf:8.2f} TOp/s  best {2.0*s**3/best/1e12:8.2f}",
+                          flush=True)
+            if key in knob:
+                g.set_tuning(knob[key], -1)
 
 
 if __name__ == "__main__":
