@@ -79,38 +79,64 @@ def build(verbose=True):
 
     host_dir = os.path.join(HERE, "host")
     host_jobs = []
+    shim_jobs = []
     host_hdrs = [os.path.join(host_dir, f) for f in os.listdir(host_dir) if f.endswith(".h")] + [
         os.path.join(ROOT, "include", "mm_gemm.h")]
-    rpath = "-Wl,-rpath,$ORIGIN/../gemm_hls_amd"
-    for (dt, mp, rd) in HOST_CONFIGS:
-        names = [f"RunHardware_{dt}_{mp}_{rd}.exe"] + (["RunHardware.exe"] if (dt, mp, rd) == HOST_CONFIGS[0] else [])
-        src = os.path.join(host_dir, "RunHardware.cpp")
-        if not os.path.exists(src):
-            break
-        for name in names:
-            out = os.path.join(BIN, name)
-            if newer(out, [src, LIB] + host_hdrs + [__file__]):
-                # amdclang++ (not g++): the host needs _Float16 for MM_DATA_TYPE=half
-                host_jobs.append(["/opt/rocm/lib/llvm/bin/clang++", "-O2", "-std=c++17", "-pthread",
-                                  f"-DMM_DATA_TYPE={dt}", f"-DMM_MAP_OP={mp}", f"-DMM_REDUCE_OP={rd}",
-                                  "-DMM_DYNAMIC_SIZES", "-I" + os.path.join(ROOT, "include"), "-I" + host_dir,
-                                  src, "-o", out, "-L" + HERE, "-lmm_gemm_amd", rpath, "-ldl"])
-    # static-size build (MM_DYNAMIC_SIZES=OFF, CMakeLists.txt:21-24): sizes baked in, argv = [mode] [verify]
-    src = os.path.join(host_dir, "RunHardware.cpp")
-    out = os.path.join(BIN, "RunHardware_static_float_528x512x560.exe")
-    if os.path.exists(src) and newer(out, [src, LIB] + host_hdrs + [__file__]):
-        host_jobs.append(["/opt/rocm/lib/llvm/bin/clang++", "-O2", "-std=c++17", "-pthread", "-DMM_DATA_TYPE=float",
-                          "-DMM_MAP_OP=Multiply", "-DMM_REDUCE_OP=Add", "-DMM_SIZE_N=528", "-DMM_SIZE_K=512",
-                          "-DMM_SIZE_M=560", "-I" + os.path.join(ROOT, "include"), "-I" + host_dir, src, "-o", out,
-                          "-L" + HERE, "-lmm_gemm_amd", rpath, "-ldl"])
-    for extra in ("PrintSpecifications", "TestSimulation"):
-        src = os.path.join(host_dir, extra + ".cpp")
-        out = os.path.join(BIN, extra + ".exe")
+    rpath = "-Wl,-rpath,$ORIGIN/../gemm_hls_amd:$ORIGIN"
+    cxx = "/opt/rocm/lib/llvm/bin/clang++"  # amdclang++ (not g++): the host needs _Float16 for MM_DATA_TYPE=half
+    common = [cxx, "-O2", "-std=c++17", "-pthread", "-I" + os.path.join(ROOT, "include"), "-I" + host_dir]
+
+    def defs(dt, mp, rd, sizes=None, transposed=False, power=False):
+        d = [f"-DMM_DATA_TYPE={dt}", f"-DMM_MAP_OP={mp}", f"-DMM_REDUCE_OP={rd}"]
+        d += ["-DMM_DYNAMIC_SIZES"] if sizes is None else [f"-DMM_SIZE_{ax}={v}" for ax, v in zip("NKM", sizes)]
+        if transposed:
+            d.append("-DMM_TRANSPOSED_A")
+        if power:
+            d.append("-DMM_POWER_METER")
+        return d
+
+    def exe(name, source, d, shim=None):
+        src = os.path.join(host_dir, source)
+        out = os.path.join(BIN, name)
+        deps = [src, LIB] + host_hdrs + [__file__] + ([os.path.join(BIN, shim)] if shim else [])
+        if os.path.exists(src) and newer(out, [p for p in deps if os.path.exists(p)] or deps):
+            # the shim goes first: its MatrixMultiplicationKernel is the one the caller binds to
+            link = (["-L" + BIN, "-l:" + shim] if shim else []) + ["-L" + HERE, "-lmm_gemm_amd", rpath, "-ldl"]
+            host_jobs.append(common + d + [src, "-o", out] + link)
+
+    def shim(name, d):
+        """Build-time configured kernel library (the reference's `mmkernel`, CMakeLists.txt:138-146)."""
+        src = os.path.join(host_dir, "KernelShim.cpp")
+        out = os.path.join(BIN, name)
         if os.path.exists(src) and newer(out, [src, LIB] + host_hdrs + [__file__]):
-            host_jobs.append(["/opt/rocm/lib/llvm/bin/clang++", "-O2", "-std=c++17", "-pthread", "-DMM_DATA_TYPE=float",
-                              "-DMM_MAP_OP=Multiply", "-DMM_REDUCE_OP=Add", "-DMM_DYNAMIC_SIZES",
-                              "-I" + os.path.join(ROOT, "include"), "-I" + host_dir, src, "-o", out,
-                              "-L" + HERE, "-lmm_gemm_amd", rpath, "-ldl"])
+            shim_jobs.append(common + d + ["-shared", "-fPIC", src, "-o", out, "-L" + HERE, "-lmm_gemm_amd",
+                                           "-Wl,-rpath,$ORIGIN/../gemm_hls_amd"])
+
+    for (dt, mp, rd) in HOST_CONFIGS:
+        exe(f"RunHardware_{dt}_{mp}_{rd}.exe", "RunHardware.cpp", defs(dt, mp, rd))
+    dt, mp, rd = HOST_CONFIGS[0]
+    exe("RunHardware.exe", "RunHardware.cpp", defs(dt, mp, rd))
+    # static-size build (MM_DYNAMIC_SIZES=OFF, CMakeLists.txt:21-24): sizes baked in, argv = [mode] [verify]
+    static = (528, 512, 560)
+    tag = "x".join(map(str, static))
+    exe(f"RunHardware_static_float_{tag}.exe", "RunHardware.cpp", defs(dt, mp, rd, static))
+    # MM_TRANSPOSED_A builds (CMakeLists.txt:30,100-103): A generated / handed over / verified as K x N
+    exe("RunHardware_transposedA_float.exe", "RunHardware.cpp", defs("float", "Multiply", "Add", transposed=True))
+    exe("RunHardware_transposedA_int.exe", "RunHardware.cpp", defs("int", "Multiply", "Add", transposed=True))
+    # MM_POWER_METER build (CMakeLists.txt:13,212-214)
+    exe("RunHardware_power.exe", "RunHardware.cpp", defs(dt, mp, rd, power=True))
+    # kernel shims + the CTest binary bound to them: dynamic, static (3-pointer symbol) and K x N A
+    shim("libmmkernel.so", defs(dt, mp, rd))
+    shim(f"libmmkernel_static_float_{tag}.so", defs(dt, mp, rd, static))
+    shim("libmmkernel_transposedA.so", defs(dt, mp, rd, transposed=True))
+    shim("libmmkernel_half.so", defs("half", mp, rd))
+    exe("TestSimulation.exe", "TestSimulation.cpp", defs(dt, mp, rd), shim="libmmkernel.so")
+    exe(f"TestSimulation_static_float_{tag}.exe", "TestSimulation.cpp", defs(dt, mp, rd, static),
+        shim=f"libmmkernel_static_float_{tag}.so")
+    exe("TestSimulation_transposedA.exe", "TestSimulation.cpp", defs(dt, mp, rd, transposed=True),
+        shim="libmmkernel_transposedA.so")
+    exe("TestSimulation_half.exe", "TestSimulation.cpp", defs("half", mp, rd), shim="libmmkernel_half.so")
+    exe("PrintSpecifications.exe", "PrintSpecifications.cpp", defs(dt, mp, rd))
     # hardware probes cited by profiles/ (stand-alone HIP programs, not part of the product)
     probe_dir = os.path.join(ROOT, "tools", "probes")
     if os.path.isdir(probe_dir):
@@ -121,6 +147,7 @@ def build(verbose=True):
                     host_jobs.append([HIPCC, "--offload-arch=" + ARCH, "-O2", "-w",
                                       os.path.join(probe_dir, f), "-o", out])
     with concurrent.futures.ThreadPoolExecutor(max_workers=os.cpu_count() or 4) as ex:
+        list(ex.map(run, shim_jobs))      # the shims first: the CTest binaries link against them
         list(ex.map(run, host_jobs))
     if verbose and host_jobs:
         print(f"built {len(host_jobs)} host binaries in {BIN}")

@@ -531,9 +531,11 @@ int mm_kernel_info(const mm_config_t *cfg, unsigned n, unsigned k, unsigned m, m
     case FAM_MFMA_F16:
       if (mm::mfma_f16_tile(p) == 4) { r.tile_n = 128; r.tile_m = 256; r.wavefronts = 4; }
       else { r.tile_n = 256; r.tile_m = 256; r.wavefronts = 8; }
-      r.tile_k = 64;
+      r.tile_k = (r.tile_n == 256 && k % 32 == 0 && k >= 128 && cfg->layout_a == MM_A_ROW_MAJOR) ? 32 : 64;
       r.inst_n = 32; r.inst_m = 32; r.inst_k = 16; r.ops_per_clk_per_cu = 4096.0;
-      r.measured_issue_efficiency = 0.60;   // profiles/r01_pmc_f16.json (and the clock drops to ~1.7 GHz)
+      // ping-pong schedule: MfmaUtil 84 % at 32768^3 (profiles/r02d_pmc_f16_32768_v11.json); the chip is
+      // power-limited there and delivers ~1.5 GHz, so 0.84 x 2.4 GHz over-predicts wall throughput
+      r.measured_issue_efficiency = r.tile_k == 32 ? 0.84 : 0.67;
       break;
     case FAM_MFMA_I8:
       r.tile_n = 256; r.tile_m = 256; r.tile_k = 128; r.wavefronts = 8;

@@ -303,7 +303,7 @@ __global__ __launch_bounds__(G::THREADS) void mfma_f16_kernel(const _Float16 *__
 // Requirements: K % 32 == 0 (the reference's own contract for half: 64-byte bus = 32 elements,
 // host/RunHardware.cpp:50-55), M % 8 == 0, row-major A.  Other shapes: the kernel above.
 struct GeoPP {
-  static constexpr int BM = 256, BN = 256, BK = 32, NS = 4, NW = 8, THREADS = 512;
+  static constexpr int BM = 256, BN = 256, BK = 32, NS = 4, THREADS = 512;
   static constexpr int TM = 4, TN = 2;  // 128 x 64 per wave
   static constexpr int A_BYTES = BM * BK * 2, B_BYTES = BK * BN * 2, STAGE_BYTES = A_BYTES + B_BYTES;
   static constexpr int LDS_BYTES = NS * STAGE_BYTES;  // 128 KiB; the epilogue needs 8 x 128 x 128 B = 128 KiB
@@ -313,7 +313,15 @@ struct GeoPP {
 // one LDS-DMA piece: 64 lanes x 16 B from (uniform base + per-lane 32-bit offset) to LDS at m0
 #define MM_DMA_PIECE(vo, sb, la) "s_mov_b32 m0, " la "\n\ts_nop 0\n\tglobal_load_lds_dwordx4 " vo ", " sb "\n\t"
 
-template <int VAR>  // bit 0: s_setprio around the MFMA segment; bit 1: lock-step ablation (no antiphase)
+// VAR bit 0: s_setprio around the MFMA segment; bit 1: lock-step ablation (no antiphase);
+// bit 2: the barrier that ends a compute segment is executed 4 MFMAs early, so the partner's first
+//        MFMAs queue up behind this wave's last ones instead of behind a barrier round trip;
+// bit 3: DMA pieces issued before (instead of after) the fragment reads of a load segment.
+// Ablations for the power breakdown (WRONG results by construction, never dispatched by default):
+// bit 4: no DMA in the main loop; bit 5: no fragment reads in the main loop (the first slab's are reused);
+// bit 6: every workgroup streams tile (0, 0)'s panels (all DMA traffic becomes L2 hits: splits the
+//        CU-side cost of the DMA path from the fabric / HBM side).
+template <int VAR>
 __global__ __launch_bounds__(GeoPP::THREADS) void mfma_f16_pp_kernel(const _Float16 *__restrict__ A,
                                                                        const _Float16 *__restrict__ B,
                                                                        _Float16 *__restrict__ C, unsigned N, unsigned K,
@@ -347,8 +355,8 @@ __global__ __launch_bounds__(GeoPP::THREADS) void mfma_f16_pp_kernel(const _Floa
     const unsigned lc = pb ^ ((kr & 3u) << 2);
     voff_b[i] = kr * M * 2 + (min(col0 + lc * 8, M - 8) - col0) * 2;
   }
-  const char *a_base = (const char *)A + (size_t)row0 * K * 2;
-  const char *b_base = (const char *)B + (size_t)col0 * 2;
+  const char *a_base = (const char *)A + ((VAR & 64) ? 0 : (size_t)row0 * K * 2);
+  const char *b_base = (const char *)B + ((VAR & 64) ? 0 : (size_t)col0 * 2);
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
   const unsigned U = K / G::BK;
   auto issue = [&](unsigned slab, unsigned buf) {
@@ -387,6 +395,7 @@ __global__ __launch_bounds__(GeoPP::THREADS) void mfma_f16_pp_kernel(const _Floa
 #pragma unroll
     for (int ni = 0; ni < TN; ++ni) acc[mi][ni] = (f32x16)0.0f;
 
+  h8 af_keep[TM][2], bf_keep[TN][2];  // ablation bit 5 only
   auto sync = [&]() {
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
@@ -395,8 +404,10 @@ __global__ __launch_bounds__(GeoPP::THREADS) void mfma_f16_pp_kernel(const _Floa
   // one slab: load segment | barrier | compute segment | barrier
   auto phase = [&](auto bufc, unsigned u) {
     constexpr int BUF = decltype(bufc)::value;
-    const char *base = smem + BUF * G::STAGE_BYTES;
+    const char *base = smem + ((VAR & 32) ? 0 : BUF) * G::STAGE_BYTES;
     h8 af[TM][2], bf[TN][2];
+    if ((VAR & 8) && !(VAR & 16)) issue(u + 3, (BUF + 3) & 3);
+    if (!(VAR & 32) || u == 0) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
@@ -409,19 +420,40 @@ __global__ __launch_bounds__(GeoPP::THREADS) void mfma_f16_pp_kernel(const _Floa
 #pragma unroll
       for (int mi = 0; mi < TM; ++mi) af[mi][ks] = *(const h8 *)(base + a_off[ks] + mi * 32 * (G::BK * 2));
     }
-    issue(u + 3, (BUF + 3) & 3);
+    if (VAR & 32) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) af_keep[mi][ks] = af[mi][ks];
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) bf_keep[ni][ks] = bf[ni][ks];
+      }
+    }
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) af[mi][ks] = af_keep[mi][ks];
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) bf[ni][ks] = bf_keep[ni][ks];
+      }
+    }
+    if (!(VAR & 8) && !(VAR & 16)) issue(u + 3, (BUF + 3) & 3);
     asm volatile("s_waitcnt vmcnt(8)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");  // own pieces of slab u+1 landed; fragments in registers
     sync();
     if (VAR & 1) __builtin_amdgcn_s_setprio(1);
+    constexpr int EARLY = (VAR & 4) ? 4 : 0;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < TN; ++ni)
+        for (int ni = 0; ni < TN; ++ni) {
+          if (EARLY && ks * 8 + mi * 2 + ni == 16 - EARLY) sync();
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mi][ks], bf[ni][ks], acc[mi][ni], 0, 0, 0);
+        }
     if (VAR & 1) __builtin_amdgcn_s_setprio(0);
-    sync();
+    if (!EARLY) sync();
   };
 
   // ---- prologue: 3 slabs in flight, slab 0 published -------------------------------------------------
@@ -507,19 +539,32 @@ int launch_mfma_f16(hipStream_t s, const Problem &p) {
   if (!mfma_f16_serves(p)) return kErrNotSupported;
   if (p.a_transposed) return launch_h<GeoH, true>(s, p);
   const int v = tuning(TUNE_F16_VARIANT);  // tuning hook
-  if (v >= 10 && v <= 13 && mfma_f16_pp_serves(p)) {
-    switch (v) {
-      case 10: return launch_pp<0>(s, p);
-      case 11: return launch_pp<1>(s, p);
-      case 12: return launch_pp<2>(s, p);
-      default: return launch_pp<3>(s, p);
+  if (v >= 10 && mfma_f16_pp_serves(p)) {  // 10 + VAR of the ping-pong kernel
+    switch (v - 10) {
+      case 0: return launch_pp<0>(s, p);
+      case 1: return launch_pp<1>(s, p);
+      case 2: return launch_pp<2>(s, p);
+      case 3: return launch_pp<3>(s, p);
+      case 4: return launch_pp<4>(s, p);
+      case 5: return launch_pp<5>(s, p);
+      case 9: return launch_pp<9>(s, p);
+      case 13: return launch_pp<13>(s, p);
+      case 17: return launch_pp<17>(s, p);  // ablation: no DMA
+      case 33: return launch_pp<33>(s, p);  // ablation: no fragment reads
+      case 49: return launch_pp<49>(s, p);  // ablation: neither
+      case 65: return launch_pp<65>(s, p);  // ablation: every workgroup streams the same panels (L2-resident)
+      default: return kErrNotSupported;
     }
   }
   if (v == 1) return launch_h<GeoH4>(s, p);
   if (v == 2) return launch_h<GeoH32x4>(s, p);
   if (v == 3) return launch_h<GeoH32x3>(s, p);
   if (v == 4) return launch_h<GeoHS>(s, p);
-  if (v < 0 && mfma_f16_tile(p) == 4) return launch_h<GeoHS>(s, p);
+  if (v == 0) return launch_h<GeoH>(s, p);
+  // default: the shape-adaptive tile pick; where that is the 256 x 256 tile and the shape allows it,
+  // the ping-pong schedule (84-89 % MFMA utilisation vs 67 %, profiles/r02d_pmc_f16_32768_v*.json)
+  if (mfma_f16_tile(p) == 4) return launch_h<GeoHS>(s, p);
+  if (mfma_f16_pp_serves(p)) return launch_pp<1>(s, p);
   return launch_h<GeoH>(s, p);
 }
 

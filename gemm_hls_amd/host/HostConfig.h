@@ -1,6 +1,7 @@
 // Build-time configuration of the host binaries, the counterpart of the reference's generated
 // Config.h (include/Config.h.in:15-35): -DMM_DATA_TYPE=<type> -DMM_MAP_OP=<Op> -DMM_REDUCE_OP=<Op>
-// [-DMM_MEMORY_BUS_WIDTH_K=64 -DMM_MEMORY_BUS_WIDTH_M=64] [-DMM_DYNAMIC_SIZES | -DMM_SIZE_N=..].
+// [-DMM_MEMORY_BUS_WIDTH_K=64 -DMM_MEMORY_BUS_WIDTH_M=64] [-DMM_DYNAMIC_SIZES | -DMM_SIZE_N=..]
+// [-DMM_TRANSPOSED_A] [-DMM_POWER_METER].
 // The device library itself is runtime-dispatched; these macros pick the configuration this
 // binary drives, exactly one per binary as in the reference.
 #pragma once
@@ -26,6 +27,9 @@
 #ifndef MM_MEMORY_BUS_WIDTH_M
 #define MM_MEMORY_BUS_WIDTH_M 64
 #endif
+#ifndef MM_MEMORY_BUS_WIDTH_N
+#define MM_MEMORY_BUS_WIDTH_N 64
+#endif
 
 using half = _Float16;  // MM_DATA_TYPE=half (CMakeLists.txt:44-45)
 using Data_t = MM_DATA_TYPE;
@@ -33,6 +37,15 @@ using Data_t = MM_DATA_TYPE;
 constexpr int kSeed = 5;  // include/MatrixMultiplication.h:14
 constexpr int kMemoryWidthK = MM_MEMORY_BUS_WIDTH_K / sizeof(Data_t);  // MatrixMultiplication.h:18
 constexpr int kMemoryWidthM = MM_MEMORY_BUS_WIDTH_M / sizeof(Data_t);  // MatrixMultiplication.h:24
+// MM_TRANSPOSED_A (CMakeLists.txt:30,100-103): A is handed over as K x N; the host oracle indexes it
+// that way (include/Utility.h:31-35) and the kernel's first parameter becomes MemoryPackN_t
+// (include/MatrixMultiplication.h:46-66,156-162).
+#ifdef MM_TRANSPOSED_A
+constexpr bool kTransposedA = true;
+constexpr int kMemoryWidthN = MM_MEMORY_BUS_WIDTH_N / sizeof(Data_t);  // MatrixMultiplication.h:49
+#else
+constexpr bool kTransposedA = false;
+#endif
 #ifndef MM_DYNAMIC_SIZES
 #ifndef MM_SIZE_N
 #define MM_SIZE_N 512

@@ -56,13 +56,14 @@ void Naive(const T *a, const T *b, T *c, unsigned size_n, unsigned size_k, unsig
 // binary16 with a wide accumulator and ONE final rounding: the documented contract of the MFMA
 // half path (the reference accumulates in half and overflows to inf beyond K ~ 2000 on its own
 // [1,10) inputs).
-inline void NaiveHalfWide(const half *a, const half *b, half *c, unsigned size_n, unsigned size_k, unsigned size_m) {
+inline void NaiveHalfWide(const half *a, const half *b, half *c, unsigned size_n, unsigned size_k, unsigned size_m,
+                          bool a_transposed = false) {
   ParallelRows(size_n, [=](unsigned r0, unsigned r1) {
     std::vector<double> acc(size_m);
     for (unsigned n = r0; n < r1; ++n) {
       std::fill(acc.begin(), acc.end(), 0.0);
       for (unsigned k = 0; k < size_k; ++k) {
-        const double av = (double)a[(size_t)n * size_k + k];
+        const double av = (double)(a_transposed ? a[(size_t)k * size_n + n] : a[(size_t)n * size_k + k]);
         const half *brow = b + (size_t)k * size_m;
         for (unsigned m = 0; m < size_m; ++m) acc[m] += av * (double)brow[m];
       }
@@ -81,6 +82,9 @@ struct Blas {
   static Blas &Get() {
     static Blas blas = [] {
       Blas b;
+#ifdef MM_DISABLE_BLAS_AT_BUILD  // -DMM_ENABLE_BLAS=OFF (CMakeLists.txt:14 in the reference)
+      return b;
+#endif
       if (std::getenv("MM_DISABLE_BLAS")) return b;
       struct Cand { const char *path, *s, *d; };
       std::vector<Cand> cands;
@@ -105,35 +109,49 @@ struct Blas {
 };
 constexpr int kCblasRowMajor = 101, kCblasNoTrans = 111, kCblasTrans = 112;
 
-// ReferenceImplementation: BLAS for (Multiply, Add) on float/double, Naive otherwise.
+// ReferenceImplementation: BLAS for (Multiply, Add) on float/double, Naive otherwise
+// (include/Utility.h:66-111).  `a_transposed`: A is K x N (MM_TRANSPOSED_A); the BLAS call then takes
+// CblasTrans with lda = size_n -- the reference passes lda = size_k there (include/Utility.h:86-87,
+// 99-100), which is only right when N == K; this is the corrected call.
+// `half_accumulate`: for Data_t = half, use the reference's own semantics (Naive accumulating in
+// binary16) instead of the wide-accumulate contract of the fast path: what RunHardware's hw_emu
+// mode (MM_PATH_ORDERED) reproduces bit for bit.
 template <typename T, class Map, class Reduce>
-void ReferenceImplementation(const T *a, const T *b, T *c, unsigned size_n, unsigned size_k, unsigned size_m) {
+void ReferenceImplementation(const T *a, const T *b, T *c, unsigned size_n, unsigned size_k, unsigned size_m,
+                             bool a_transposed = false, bool half_accumulate = false) {
   constexpr bool mul_add = Map::code == MM_OP_MULTIPLY && Reduce::code == MM_OP_ADD;
+  const int trans_a = a_transposed ? kCblasTrans : kCblasNoTrans;
+  const int lda = a_transposed ? size_n : size_k;
   if constexpr (mul_add && std::is_same<T, float>::value) {
     if (Blas::Get().sgemm) {
       std::cout << "Running BLAS...\n" << std::flush;
-      Blas::Get().sgemm(kCblasRowMajor, kCblasNoTrans, kCblasNoTrans, size_n, size_m, size_k, 1.0f, a, size_k, b, size_m,
-                        0.0f, c, size_m);
+      Blas::Get().sgemm(kCblasRowMajor, trans_a, kCblasNoTrans, size_n, size_m, size_k, 1.0f, a, lda, b, size_m, 0.0f, c,
+                        size_m);
       return;
     }
   }
   if constexpr (mul_add && std::is_same<T, double>::value) {
     if (Blas::Get().dgemm) {
       std::cout << "Running BLAS...\n" << std::flush;
-      Blas::Get().dgemm(kCblasRowMajor, kCblasNoTrans, kCblasNoTrans, size_n, size_m, size_k, 1.0, a, size_k, b, size_m, 0.0,
-                        c, size_m);
+      Blas::Get().dgemm(kCblasRowMajor, trans_a, kCblasNoTrans, size_n, size_m, size_k, 1.0, a, lda, b, size_m, 0.0, c,
+                        size_m);
       return;
     }
   }
   if constexpr (mul_add && IsHalf<T>::value) {
-    std::cout << "Running wide-accumulate half reference (f32-accumulate contract of the MFMA path)...\n" << std::flush;
-    NaiveHalfWide(a, b, c, size_n, size_k, size_m);
+    if (!half_accumulate) {
+      std::cout << "Running wide-accumulate half reference (f32-accumulate contract of the MFMA path)...\n" << std::flush;
+      NaiveHalfWide(a, b, c, size_n, size_k, size_m, a_transposed);
+      return;
+    }
+    std::cout << "Running half-accumulating reference (the reference's own Naive semantics)...\n" << std::flush;
+    Naive<Map, Reduce>(a, b, c, size_n, size_k, size_m, a_transposed);
     return;
   }
   std::cout << "WARNING: BLAS not available, so I'm falling back on a naive implementation. This will take a long time "
                "for large matrix sizes.\n"
             << std::flush;
-  Naive<Map, Reduce>(a, b, c, size_n, size_k, size_m);
+  Naive<Map, Reduce>(a, b, c, size_n, size_k, size_m, a_transposed);
 }
 
 // Comparison rule of test/TestSimulation.cpp:75-92 / host/RunHardware.cpp:208-225:
@@ -148,10 +166,11 @@ template <typename T> double DefaultTolerance() {
   return 0.0;
 }
 
-// returns true on success; prints the reference's mismatch line otherwise
+// returns true on success; prints the reference's mismatch line otherwise.  `exact`: compare bit
+// patterns' values exactly whatever the type (the reference's rule for half, test/TestSimulation.cpp:81-85).
 template <typename T>
-bool Verify(const T *test, const T *ref, unsigned size_n, unsigned size_m) {
-  const double tol = DefaultTolerance<T>();
+bool Verify(const T *test, const T *ref, unsigned size_n, unsigned size_m, bool exact = false) {
+  const double tol = exact ? 0.0 : DefaultTolerance<T>();
   for (size_t i = 0; i < size_n; ++i) {
     for (size_t j = 0; j < size_m; ++j) {
       const T tv = test[i * size_m + j], rv = ref[i * size_m + j];

@@ -11,6 +11,11 @@
 //   on/off  verify against ReferenceImplementation (BLAS / Naive) or time only.  With `off` the
 //           reference leaves device memory uninitialised; here it is filled on the device with
 //           the same value distribution so that clocks behave like a real run.
+// Build flags (the reference's CMake options of the same names, CMakeLists.txt:21-36): MM_DYNAMIC_SIZES
+// / MM_SIZE_{N,K,M}; MM_TRANSPOSED_A (A generated, handed over and verified as K x N); MM_POWER_METER
+// (sample the GPU's power while the kernel runs and print the reference's "Measured an average power
+// of ... W" line, host/RunHardware.cpp:156-172,182-185 -- the board's own sensor through
+// librocm_smi64 / hwmon instead of the reference's PSU meter).
 // Environment: MM_GPUS=<g> splits the rows of C over g devices (no collective; default 1).
 #include <chrono>
 #include <cstdlib>
@@ -22,6 +27,9 @@
 #include <vector>
 
 #include "HostReference.h"
+#ifdef MM_POWER_METER
+#include "PowerMeter.h"
+#endif
 
 namespace {
 
@@ -105,14 +113,16 @@ int main(int argc, char **argv) {
   const int gpus = std::getenv("MM_GPUS") ? std::max(1, std::atoi(std::getenv("MM_GPUS"))) : 1;
 
   const mm_config_t cfg = {mmhost::DTypeOf<Data_t>::value, OperatorMap::code, OperatorReduce::code,
-                           emulation ? MM_PATH_ORDERED : MM_PATH_AUTO, MM_A_ROW_MAJOR};
+                           emulation ? MM_PATH_ORDERED : MM_PATH_AUTO, kTransposedA ? MM_A_TRANSPOSED : MM_A_ROW_MAJOR};
   const size_t count_a = (size_t)size_n * size_k, count_b = (size_t)size_k * size_m, count_c = (size_t)size_n * size_m;
 
   std::vector<Data_t> a, b, cRef, cTest;
   std::cout << "Initializing host memory..." << std::flush;
   if (verify || gpus > 1) {
     // The reference's generator: ONE engine seeded with kSeed, real or integer uniform on [1, 10],
-    // all of A drawn first, then all of B (host/RunHardware.cpp:31-35,99-105).
+    // all of A drawn first, then all of B (host/RunHardware.cpp:31-35,99-105).  With MM_TRANSPOSED_A
+    // the same N*K draws ARE the K x N matrix (the reference fills one flat vector and lets the
+    // kernel and Naive index it as a[k * N + n], include/Utility.h:31-35).
     std::default_random_engine rng(kSeed);
     typename std::conditional<std::is_integral<Data_t>::value, std::uniform_int_distribution<unsigned long>,
                               std::uniform_real_distribution<double>>::type dist(1, 10);
@@ -132,6 +142,11 @@ int main(int argc, char **argv) {
     if (gpus > device_count) throw std::runtime_error("MM_GPUS exceeds the number of visible devices");
 
     double elapsed = 0.0;
+#ifdef MM_POWER_METER
+    double average_power = 0.0;
+    size_t power_samples = 0;
+    std::string power_source = "no single-device launch";
+#endif
     if (gpus > 1) {
       std::cout << "Initializing device memory on " << gpus << " devices, copying row slabs of A and C and replicas of B...\n"
                 << std::flush;
@@ -156,8 +171,26 @@ int main(int argc, char **argv) {
       if (!verify) {  // timing run: one untimed launch first so that code upload is not in the number
         Check(mm_gemm_launch(0, &cfg, aDevice.ptr, bDevice.ptr, cDevice.ptr, size_n, size_k, size_m, nullptr), "warm-up");
       }
+#ifdef MM_POWER_METER
+      mmhost::PowerMeter pm(0, 2);  // device 0, 2 ms sampling period (the reference samples its PSU every 10 ms)
+      pm.Start();
+#endif
       Check(mm_gemm_launch(0, &cfg, aDevice.ptr, bDevice.ptr, cDevice.ptr, size_n, size_k, size_m, &elapsed),
             "mm_gemm_launch");
+#ifdef MM_POWER_METER
+      // A GPU kernel is over in milliseconds, shorter than the sensor's own averaging window: keep the
+      // same launch running (untimed) until at least MM_POWER_WINDOW_MS (default 500) were sampled.
+      {
+        const char *w = std::getenv("MM_POWER_WINDOW_MS");
+        const double window = (w ? std::atof(w) : 500.0) * 1e-3;
+        while (pm.Elapsed() < window)
+          Check(mm_gemm_launch(0, &cfg, aDevice.ptr, bDevice.ptr, cDevice.ptr, size_n, size_k, size_m, nullptr), "power window");
+      }
+      pm.Stop();
+      average_power = pm.Average();
+      power_samples = pm.Samples();
+      power_source = pm.Source();
+#endif
       if (verify) {
         std::cout << "Copying back result...\n" << std::flush;
         Check(mm_copy_to_host(0, cTest.data(), cDevice.ptr, cDevice.bytes), "copy back");
@@ -178,6 +211,12 @@ int main(int argc, char **argv) {
       std::cout << perf;
     }
     std::cout << " GOp/s.\n";
+#ifdef MM_POWER_METER
+    // the reference's line (host/RunHardware.cpp:182-185) up to "W": scripts/build_manager.py:603-604
+    // parses "([\\d\\.]+) W"; what was measured is this GPU's board power, not "the full system"
+    std::cout << "Measured an average power of " << average_power << " W for the GPU (" << power_samples << " samples, "
+              << power_source << ").\n";
+#endif
   } catch (std::runtime_error const &err) {
     std::cerr << "Execution failed with error: \"" << err.what() << "\"." << std::endl;
     return 1;
@@ -186,12 +225,15 @@ int main(int argc, char **argv) {
   if (verify) {
     std::cout << "Running reference implementation...\n" << std::flush;
     const auto t0 = std::chrono::steady_clock::now();
+    // hw_emu runs the k-ordered kernel, which follows the reference's Naive to the bit -- for half
+    // that means accumulating in binary16, so it is checked against exactly that, exactly
+    const bool half_emulation = emulation && mmhost::IsHalf<Data_t>::value;
     mmhost::ReferenceImplementation<Data_t, OperatorMap, OperatorReduce>(a.data(), b.data(), cRef.data(), size_n, size_k,
-                                                                         size_m);
+                                                                         size_m, kTransposedA, half_emulation);
     const double tref = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     std::cout << "Reference implementation took " << tref << " seconds on " << mmhost::HostThreads() << " host threads.\n";
     std::cout << "Verifying result...\n" << std::flush;
-    if (!mmhost::Verify(cTest.data(), cRef.data(), size_n, size_m)) return 1;
+    if (!mmhost::Verify(cTest.data(), cRef.data(), size_n, size_m, half_emulation)) return 1;
     std::cout << "Successfully verified." << std::endl;
   }
   return 0;

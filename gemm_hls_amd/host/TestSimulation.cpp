@@ -2,15 +2,26 @@
 // behind the symbol it calls.  Command line, size checks and messages are the reference's:
 //     TestSimulation N K M        -> "Running simulation...", "Verifying results...",
 //                                    "Matrix-matrix multiplication successfully verified."
-// The single call MatrixMultiplicationKernel(a, b, c, N, K, M) takes HOST pointers; in the
-// reference it runs the HLS kernel as host threads, here libmm_gemm_amd.so exports the symbol and
-// it runs on MI355X device 0 with this build's MM_DATA_TYPE / MM_MAP_OP / MM_REDUCE_OP.
+// The single call MatrixMultiplicationKernel(a, b, c[, N, K, M]) takes HOST pointers; in the
+// reference it runs the HLS kernel as host threads (the `mmkernel` library, CMakeLists.txt:138-146),
+// here it binds to this build's kernel shim (host/KernelShim.cpp, same configuration macros, same
+// signature incl. the 3-pointer static-size form) and runs on MI355X device 0.
 #include <iostream>
 #include <random>
 #include <string>
 #include <vector>
 
+#define MM_GEMM_NO_KERNEL_SYMBOL  // the typed declaration below is the reference's (MatrixMultiplication.h:155-171)
 #include "HostReference.h"
+
+extern "C" {
+#ifdef MM_DYNAMIC_SIZES
+void MatrixMultiplicationKernel(Data_t const a[], Data_t const b[], Data_t c[], const unsigned size_n,
+                                const unsigned size_k, const unsigned size_m);
+#else
+void MatrixMultiplicationKernel(Data_t const a[], Data_t const b[], Data_t c[]);
+#endif
+}
 
 namespace {
 
@@ -61,17 +72,16 @@ int main(int argc, char **argv) {
   std::vector<Data_t> a(static_cast<size_t>(sz.n) * sz.k), b(static_cast<size_t>(sz.k) * sz.m);
   SeededInputs(a, b);
   std::vector<Data_t> expected(static_cast<size_t>(sz.n) * sz.m, Data_t(0)), computed(expected.size(), Data_t(0));
+  // MM_TRANSPOSED_A: the N*K draws are read as a K x N matrix by both sides (include/Utility.h:31-35)
   mmhost::ReferenceImplementation<Data_t, OperatorMap, OperatorReduce>(a.data(), b.data(), expected.data(), sz.n, sz.k,
-                                                                       sz.m);
+                                                                       sz.m, kTransposedA);
 
-  const mm_config_t config = {mmhost::DTypeOf<Data_t>::value, OperatorMap::code, OperatorReduce::code, MM_PATH_AUTO,
-                              MM_A_ROW_MAJOR};
-  if (mm_set_default_config(&config) != MM_OK) {
-    std::cerr << mm_last_error() << std::endl;
-    return 1;
-  }
   std::cout << "Running simulation...\n" << std::flush;
+#ifdef MM_DYNAMIC_SIZES
   MatrixMultiplicationKernel(a.data(), b.data(), computed.data(), sz.n, sz.k, sz.m);
+#else
+  MatrixMultiplicationKernel(a.data(), b.data(), computed.data());
+#endif
   std::cout << "Verifying results...\n" << std::flush;
   if (!mmhost::Verify(computed.data(), expected.data(), sz.n, sz.m)) return 1;
   std::cout << "Matrix-matrix multiplication successfully verified.\n";

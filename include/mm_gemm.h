@@ -142,8 +142,11 @@ int mm_gemm_multi_device(int device_count, const mm_config_t *cfg, const void *a
  * configuration set by mm_set_default_config (initially float, Multiply, Add == the
  * reference's CMake defaults).  Errors are reported on stderr and abort(), because the
  * reference's symbol returns void. */
+#ifndef MM_GEMM_NO_KERNEL_SYMBOL /* defined by translation units that declare the reference's typed
+                                    or 3-pointer form themselves (host/KernelShim.cpp and its callers) */
 void MatrixMultiplicationKernel(const void *a, const void *b, void *c, unsigned size_n,
                                 unsigned size_k, unsigned size_m);
+#endif
 int mm_set_default_config(const mm_config_t *cfg);
 /* The same host-pointer call with an explicit configuration and a status instead of abort().
  * This is what the build-time-configured kernel shim (gemm_hls_amd/host/KernelShim.cpp: one

@@ -1,0 +1,83 @@
+"""The CMake configuration surface (CMakeLists.txt at the repo root): the reference's cache
+variables (CMakeLists.txt:8-36 there) configure and build the host side here.  The device library
+is taken pre-built (-DMM_PREBUILT_LIBRARY, what gemm_hls_amd/build.py produced) so that this stays
+a seconds-long CPU test; the full path -- hipcc custom commands for every kernel -- is the same
+file without that option."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "gemm_hls_amd", "libmm_gemm_amd.so")
+
+pytestmark = pytest.mark.skipif(shutil.which("cmake") is None, reason="cmake not installed")
+
+
+def _configure(tmp_path, *defs):
+    build = tmp_path / "build"
+    cmd = ["cmake", "-S", ROOT, "-B", str(build), f"-DMM_PREBUILT_LIBRARY={LIB}", *defs]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    return build, r
+
+
+def _build(build):
+    r = subprocess.run(["cmake", "--build", str(build), "-j", "8"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+def test_default_configuration_builds_the_reference_targets(tmp_path):
+    build, r = _configure(tmp_path)
+    assert r.returncode == 0, r.stdout + r.stderr
+    _build(build)
+    for name in ("RunHardware.exe", "TestSimulation", "PrintSpecifications", "libmmkernel.so"):
+        assert (build / name).exists(), name
+    u = subprocess.run([str(build / "RunHardware.exe")], capture_output=True, text=True)
+    assert u.returncode == 1 and "Usage: ./RunHardware.exe N K M [<mode [hw/hw_emu]>] [<verify [on/off]>]" in u.stderr
+    # CTest is registered with the reference's sizes: 2*256+1, 2*32*8+64/4, 2*256+16 (CMakeLists.txt:155-159)
+    t = subprocess.run(["ctest", "-N", "-V"], cwd=build, capture_output=True, text=True)
+    assert "TestSimulation" in t.stdout and "513" in t.stdout and "528" in t.stdout
+
+
+def test_static_half_transposed_power_configuration(tmp_path):
+    build, r = _configure(tmp_path, "-DMM_DATA_TYPE=half", "-DMM_DYNAMIC_SIZES=OFF", "-DMM_SIZE_N=528", "-DMM_SIZE_K=512",
+                          "-DMM_SIZE_M=576", "-DMM_TRANSPOSED_A=ON", "-DMM_POWER_METER=ON", "-DMM_MAP_OP=Multiply",
+                          "-DMM_REDUCE_OP=Add", "-DMM_PLATFORM=xilinx_u250", "-DMM_PARALLELISM_N=16")
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "FPGA build option of the reference; ignored" in r.stdout
+    _build(build)
+    u = subprocess.run([str(build / "RunHardware.exe"), "hw", "on", "extra"], capture_output=True, text=True)
+    assert u.returncode == 1 and "Usage: ./RunHardware.exe <mode [hw/hw_emu]> [<verify [on/off]>]" in u.stderr
+    import ctypes
+    shim = ctypes.CDLL(str(build / "libmmkernel.so"))
+    n, k, m = ctypes.c_uint(), ctypes.c_uint(), ctypes.c_uint()
+    shim.MatrixMultiplicationKernelSizes(ctypes.byref(n), ctypes.byref(k), ctypes.byref(m))
+    assert (n.value, k.value, m.value) == (528, 512, 576)
+
+
+@pytest.mark.parametrize("defs,msg", [(("-DMM_DATA_TYPE=quaternion",), "Could not get size of data type"),
+                                      (("-DMM_MAP_OP=Divide",), "must be one of"),
+                                      (("-DMM_DYNAMIC_SIZES=OFF", "-DMM_SIZE_K=100"), "divisible by the memory bus width")])
+def test_configuration_errors_are_reported_at_configure_time(tmp_path, defs, msg):
+    _, r = _configure(tmp_path, *defs)
+    assert r.returncode != 0 and msg in (r.stdout + r.stderr)
+
+
+def test_full_build_description_compiles_every_kernel_source():
+    """Without MM_PREBUILT_LIBRARY every .hip under gemm_hls_amd/csrc gets a hipcc command (checked on
+    the generated build system, not executed here: that is minutes of compilation)."""
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        r = subprocess.run(["cmake", "-S", ROOT, "-B", d], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        mk = open(os.path.join(d, "Makefile")).read() + open(os.path.join(d, "CMakeFiles", "Makefile2")).read()
+        rules = ""
+        for root, _, files in os.walk(os.path.join(d, "CMakeFiles")):
+            for f in files:
+                if f == "build.make":
+                    rules += open(os.path.join(root, f)).read()
+        for src in os.listdir(os.path.join(ROOT, "gemm_hls_amd", "csrc")):
+            if src.endswith(".hip"):
+                assert src in rules, src
+        assert "--offload-arch=gfx950" in rules and "-ffp-contract=off" in rules and "libmm_gemm_amd.so" in rules

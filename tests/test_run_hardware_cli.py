@@ -77,11 +77,70 @@ BUILD_MANAGER_RE = re.compile(r"([\d\.]+) seconds[^\d]+([\d\.]+) GOp/s")
 ])
 @pytest.mark.parametrize("mode", ["hw", "hw_emu"])
 def test_run_hardware_verifies_on_gpu(exe, shape, mode):
-    if "half" in exe and mode == "hw_emu":
-        pytest.skip("hw_emu accumulates in half like the reference; the host check uses the wide contract")
     r = run(os.path.join(ROOT, "bin", exe), *shape, mode, "on")
     assert r.returncode == 0, r.stdout + r.stderr
     assert PERF_LINE.search(r.stdout) and "Successfully verified." in r.stdout
+    if "half" in exe:
+        # hw: f32-accumulate contract vs the wide reference; hw_emu: the reference's own half-accumulating
+        # Naive, compared EXACTLY as the reference compares half (test/TestSimulation.cpp:81-85)
+        want = "half-accumulating reference" if mode == "hw_emu" else "wide-accumulate half reference"
+        assert want in r.stdout
+
+
+@pytest.mark.gpu
+def test_half_hw_emu_is_exact_even_where_half_accumulation_overflows():
+    """K = 4096 on [1,10) data: the reference's half semantics give inf everywhere; hw_emu must
+    reproduce exactly that and the exact comparison must accept inf == inf."""
+    r = run(os.path.join(ROOT, "bin", "RunHardware_half_Multiply_Add.exe"), 65, 4096, 64, "hw_emu", "on")
+    assert r.returncode == 0 and "Successfully verified." in r.stdout, r.stdout + r.stderr
+
+
+# ---- MM_TRANSPOSED_A builds (CMakeLists.txt:30,100-103; include/Utility.h:31-35) ------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("exe,shape", [("RunHardware_transposedA_float.exe", (516, 528, 528)),
+                                       ("RunHardware_transposedA_float.exe", (300, 64, 272)),   # N != K: the lda the reference gets wrong
+                                       ("RunHardware_transposedA_int.exe", (260, 272, 272))])
+@pytest.mark.parametrize("mode", ["hw", "hw_emu"])
+def test_transposed_a_build_verifies_on_gpu(exe, shape, mode):
+    r = run(os.path.join(ROOT, "bin", exe), *shape, mode, "on")
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "Successfully verified." in r.stdout
+
+
+def test_transposed_a_build_keeps_the_cli():
+    exe = os.path.join(ROOT, "bin", "RunHardware_transposedA_float.exe")
+    assert run(exe).returncode == 1 and USAGE in run(exe).stderr
+    r = run(exe, 64, 17, 64)
+    assert r.returncode == 1 and "K (17) must be divisable by the memory width in K (16)." in r.stderr
+
+
+@pytest.mark.gpu
+def test_test_simulation_transposed_a_and_half_on_gpu():
+    r = run(os.path.join(ROOT, "bin", "TestSimulation_transposedA.exe"), 516, 528, 528)
+    assert r.returncode == 0 and "successfully verified" in r.stdout, r.stdout + r.stderr
+    r = run(os.path.join(ROOT, "bin", "TestSimulation_half.exe"), 129, 160, 288)
+    assert r.returncode == 0 and "successfully verified" in r.stdout, r.stdout + r.stderr
+
+
+# ---- MM_POWER_METER build (CMakeLists.txt:13,212-214; host/RunHardware.cpp:156-172,182-185) ------------------
+# the second regex of the reference's benchmark parser (scripts/build_manager.py:603-604)
+POWER_RE = re.compile(r"([\d\.]+) W")
+
+
+@pytest.mark.gpu
+def test_power_meter_build_samples_while_the_kernel_runs():
+    r = run(os.path.join(ROOT, "bin", "RunHardware_power.exe"), 8192, 8192, 8192, "hw", "off",
+            env={"MM_POWER_WINDOW_MS": "400"})
+    assert r.returncode == 0, r.stdout + r.stderr
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("Measured an average power of")]
+    assert line and PERF_LINE.search(r.stdout)
+    m = POWER_RE.search(line[0])
+    samples = int(re.search(r"\((\d+) samples", line[0]).group(1))
+    assert m and samples >= 20, line
+    watts = float(m.group(1))
+    # an MI355X multiplying flat out draws several hundred watts; idle is ~150 W.  A sensor that is
+    # missing reports 0 samples and fails above; this bound catches a sample taken on an idle chip
+    assert 250.0 < watts < 1600.0, line
 
 
 @pytest.mark.gpu
@@ -126,6 +185,38 @@ def test_test_simulation_cli_errors():
     assert r.returncode == 1 and "K must be divisable by memory width." in r.stderr
     r = run(exe, 64, 16, 17)
     assert r.returncode == 1 and "M must be divisable by memory width." in r.stderr
+
+
+def test_kernel_shims_export_the_reference_symbol_for_their_configuration():
+    """The build-time configured kernel libraries: dynamic = 6 arguments, static = the 3-pointer
+    form with the sizes baked in (include/MatrixMultiplication.h:155-169)."""
+    import ctypes
+    dyn = ctypes.CDLL(os.path.join(ROOT, "bin", "libmmkernel.so"))
+    assert dyn.MatrixMultiplicationKernel is not None and not hasattr(dyn, "MatrixMultiplicationKernelSizes")
+    st = ctypes.CDLL(os.path.join(ROOT, "bin", "libmmkernel_static_float_528x512x560.so"))
+    n, k, m = ctypes.c_uint(), ctypes.c_uint(), ctypes.c_uint()
+    st.MatrixMultiplicationKernelSizes(ctypes.byref(n), ctypes.byref(k), ctypes.byref(m))
+    assert (n.value, k.value, m.value) == (528, 512, 560)
+    # the symbol of the shim is its own definition, not the run-time configured one of libmm_gemm_amd.so
+    import gemm_hls_amd as g
+    addr = lambda lib: ctypes.cast(lib.MatrixMultiplicationKernel, ctypes.c_void_p).value
+    assert len({addr(dyn), addr(st), addr(g.lib())}) == 3
+
+
+@pytest.mark.gpu
+def test_static_kernel_shim_three_pointer_call_on_gpu():
+    import ctypes
+    import numpy as np
+    import _oracle
+    st = ctypes.CDLL(os.path.join(ROOT, "bin", "libmmkernel_static_float_528x512x560.so"))
+    st.MatrixMultiplicationKernel.argtypes = [ctypes.c_void_p] * 3
+    st.MatrixMultiplicationKernel.restype = None
+    a, b = _oracle.fill("float", 528, 512, 560)
+    c = np.zeros((528, 560), np.float32)
+    st.MatrixMultiplicationKernel(a.ctypes.data, b.ctypes.data, c.ctypes.data)
+    assert _oracle.compare("float", c, a @ b, 1e-5)[0] == 0
+    r = run(os.path.join(ROOT, "bin", "TestSimulation_static_float_528x512x560.exe"))
+    assert r.returncode == 0 and "successfully verified" in r.stdout, r.stdout + r.stderr
 
 
 @pytest.mark.gpu
