@@ -114,6 +114,8 @@ def build(verbose=True):
 
     for (dt, mp, rd) in HOST_CONFIGS:
         exe(f"RunHardware_{dt}_{mp}_{rd}.exe", "RunHardware.cpp", defs(dt, mp, rd))
+        # MM_POWER_METER builds (CMakeLists.txt:13,212-214), what tools/benchmark.py drives
+        exe(f"RunHardware_{dt}_{mp}_{rd}_power.exe", "RunHardware.cpp", defs(dt, mp, rd, power=True))
     dt, mp, rd = HOST_CONFIGS[0]
     exe("RunHardware.exe", "RunHardware.cpp", defs(dt, mp, rd))
     # static-size build (MM_DYNAMIC_SIZES=OFF, CMakeLists.txt:21-24): sizes baked in, argv = [mode] [verify]
@@ -123,7 +125,6 @@ def build(verbose=True):
     # MM_TRANSPOSED_A builds (CMakeLists.txt:30,100-103): A generated / handed over / verified as K x N
     exe("RunHardware_transposedA_float.exe", "RunHardware.cpp", defs("float", "Multiply", "Add", transposed=True))
     exe("RunHardware_transposedA_int.exe", "RunHardware.cpp", defs("int", "Multiply", "Add", transposed=True))
-    # MM_POWER_METER build (CMakeLists.txt:13,212-214)
     exe("RunHardware_power.exe", "RunHardware.cpp", defs(dt, mp, rd, power=True))
     # kernel shims + the CTest binary bound to them: dynamic, static (3-pointer symbol) and K x N A
     shim("libmmkernel.so", defs(dt, mp, rd))

@@ -19,6 +19,7 @@
 // Edges: N arbitrary, K % 32 == 0, M % 16 == 0 (reference contract for 1-byte types: K % 64,
 // M % 64); a K x N A (N % 16 == 0) is gathered like B; other shapes go to the predicated kernels.
 #include <cstdlib>
+#include <type_traits>
 
 #include "mm_common.h"
 
@@ -242,6 +243,168 @@ __global__ __launch_bounds__(GeoI8::THREADS) void mfma_i8_kernel(const signed ch
   }
 }
 
+
+// =================================================================================================
+// Ping-pong schedule (round 2), the int8 twin of mfma_f16_pp_kernel (mm_mfma_f16.hip -- read the
+// comment there): 64-byte-deep slabs (2 MFMA k-steps), 4-slab LDS ring of 32 KiB, waves 0-3 and 4-7
+// one barrier apart so that one wave of every SIMD multiplies while its partner reads fragments and
+// issues DMA; 8 waves as 2 x 4, 128 x 64 outputs per wave.  The A slab image is byte-for-byte the
+// f16 kernel's ([256 rows][64 B], chunk ^ (row>>2)&3, fragment = chunk 2*ks + hi); the B slab is
+// [64 k][256 B] with the transpose-read layout of the kernel above (chunk ^ (k&7)<<1).
+// Requirements: K % 64 == 0 (the reference's contract for 1-byte types), M % 16 == 0, row-major A.
+struct GeoI8PP {
+  static constexpr int BM = 256, BN = 256, BK = 64, NS = 4, THREADS = 512;
+  static constexpr int TM = 4, TN = 2;
+  static constexpr int A_BYTES = BM * BK, B_BYTES = BK * BN, STAGE_BYTES = A_BYTES + B_BYTES;
+  static constexpr int LDS_BYTES = NS * STAGE_BYTES;
+  static constexpr int BROW = BN;
+};
+#define MM_DMA_PIECE(vo, sb, la) "s_mov_b32 m0, " la "\n\ts_nop 0\n\tglobal_load_lds_dwordx4 " vo ", " sb "\n\t"
+
+template <int VAR>  // bit 1: lock-step ablation (no antiphase)
+__global__ __launch_bounds__(GeoI8PP::THREADS) void mfma_i8_pp_kernel(const signed char *__restrict__ A,
+                                                                        const signed char *__restrict__ B,
+                                                                        signed char *__restrict__ C, unsigned N, unsigned K,
+                                                                        unsigned M, unsigned tiles_n, unsigned tiles_m,
+                                                                        unsigned kBand) {
+  using G = GeoI8PP;
+  constexpr int TM = G::TM, TN = G::TN;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const unsigned lane = threadIdx.x & 63u;
+  const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const unsigned group = wave >> 2, wq = wave & 3u;
+  const unsigned wm = wq >> 1, wn = (wq & 1u) * 2 + group;
+  const unsigned lo = lane & 31u, hi = lane >> 5;
+
+  const unsigned lin = xcd_remap(blockIdx.x, tiles_n * tiles_m);
+  const unsigned band = lin / (kBand * tiles_m), within = lin % (kBand * tiles_m);
+  const unsigned rows_in_band = min(kBand, tiles_n - band * kBand);
+  const unsigned row0 = (band * kBand + within % rows_in_band) * G::BM, col0 = (within / rows_in_band) * G::BN;
+
+  unsigned voff_a[2], voff_b[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const unsigned piece = wave + 8 * i;
+    const unsigned row = piece * 16 + lane / 4, pc = lane % 4;         // 16 A pieces of 16 rows x 64 B
+    voff_a[i] = (min(row0 + row, N - 1) - row0) * K + (pc ^ ((row >> 2) & 3u)) * 16;
+    const unsigned kr = piece * 4 + lane / 16, pb = lane % 16;         // 16 B pieces of 4 k-rows x 256 B
+    const unsigned lc = pb ^ ((kr & 7u) << 1);
+    voff_b[i] = kr * M + (min(col0 + lc * 16, M - 16) - col0);
+  }
+  const char *a_base = (const char *)A + (size_t)row0 * K;
+  const char *b_base = (const char *)B + col0;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
+  const unsigned U = K / G::BK;
+  auto issue = [&](unsigned slab, unsigned buf) {
+    const unsigned sl = min(slab, U - 1);
+    const char *ap = a_base + (size_t)sl * G::BK;
+    const char *bp = b_base + (size_t)sl * G::BK * M;
+    const unsigned la0 = lds0 + buf * G::STAGE_BYTES + wave * 1024, la1 = la0 + 8 * 1024;
+    const unsigned lb0 = la0 + G::A_BYTES, lb1 = lb0 + 8 * 1024;
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\t" MM_DMA_PIECE("%1", "%5", "%7") MM_DMA_PIECE("%2", "%5", "%8")
+                     MM_DMA_PIECE("%3", "%6", "%9") MM_DMA_PIECE("%4", "%6", "%10") "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff_a[0]), "v"(voff_a[1]), "v"(voff_b[0]), "v"(voff_b[1]), "s"(ap), "s"(bp), "s"(la0), "s"(la1),
+                   "s"(lb0), "s"(lb1)
+                 : "memory");
+  };
+
+  // A fragment: row = wm*128 + mi*32 + lo, chunk (2*ks + hi) ^ ((lo>>2)&3)
+  const unsigned ca = hi ^ ((lo >> 2) & 3u);
+  const unsigned a_row_byte = (wm * 128 + lo) * G::BK;
+  const unsigned a_off[2] = {a_row_byte + ca * 16, a_row_byte + (ca ^ 2u) * 16};
+  // B fragment (8-bit transpose read): y = lane&15 -> block row r = y>>1, 8-byte half q = y&1; gq = 16-col half
+  //   k = ks*32 + 16*hi + 8*h + r ; 32-col block = wn*2 + ni, physical block = logical ^ r
+  const unsigned y = lane & 15u, gq = (lane >> 4) & 1u, r = y >> 1, q = y & 1u;
+  unsigned b_off[TN];
+#pragma unroll
+  for (int ni = 0; ni < TN; ++ni)
+    b_off[ni] = G::A_BYTES + (16 * hi + r) * G::BROW + 8 * q + ((((wn * 2 + ni) ^ r) * 2) + gq) * 16;
+
+  i32x16 acc[TM][TN];
+#pragma unroll
+  for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni) acc[mi][ni] = (i32x16)0;
+
+  auto sync = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto phase = [&](auto bufc, unsigned u) {
+    constexpr int BUF = decltype(bufc)::value;
+    const char *base = smem + BUF * G::STAGE_BYTES;
+    i32x4 af[TM][2], bf[TN][2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int ni = 0; ni < TN; ++ni) {
+        const char *p = base + b_off[ni] + ks * 32 * G::BROW;
+        const v2i v0 = __builtin_amdgcn_ds_read_tr8_b64_v2i32((v2i __attribute__((address_space(3))) *)(lptr_t)p);
+        const v2i v1 = __builtin_amdgcn_ds_read_tr8_b64_v2i32((v2i __attribute__((address_space(3))) *)(lptr_t)(p + 8 * G::BROW));
+        bf[ni][ks] = join(v0, v1);
+      }
+#pragma unroll
+      for (int mi = 0; mi < TM; ++mi) af[mi][ks] = *(const i32x4 *)(base + a_off[ks] + mi * 32 * G::BK);
+    }
+    issue(u + 3, (BUF + 3) & 3);
+    asm volatile("s_waitcnt vmcnt(8)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+    sync();
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[mi][ks], bf[ni][ks], acc[mi][ni], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    sync();
+  };
+
+  issue(0, 0);
+  issue(1, 1);
+  issue(2, 2);
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  sync();
+  const bool shifted = !(VAR & 2) && group == 1;
+  if (shifted) sync();
+  for (unsigned u = 0; u < U; u += 4) {
+    phase(std::integral_constant<int, 0>{}, u);
+    if (u + 1 < U) phase(std::integral_constant<int, 1>{}, u + 1);
+    if (u + 2 < U) phase(std::integral_constant<int, 2>{}, u + 2);
+    if (u + 3 < U) phase(std::integral_constant<int, 3>{}, u + 3);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (!shifted && !(VAR & 2)) sync();
+  sync();
+
+  // epilogue: low 8 bits of the i32 sums through this wave's 8 KiB slice, 16-B global stores
+  {
+    char *slice = smem + wave * (128 * 64);
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+          const unsigned row = mi * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * hi;
+          slice[row * 64 + ni * 32 + lo] = (char)acc[mi][ni][rr];
+        }
+    using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+#pragma unroll
+    for (int it = 0; it < 128 * 4 / 64; ++it) {
+      const unsigned c = it * 64 + lane, row = c / 4, ch = c % 4;
+      const u32x4 v = *(const u32x4 *)(slice + row * 64 + ch * 16);
+      const unsigned grow = row0 + wm * 128 + row, gcol = col0 + wn * 64 + ch * 16;
+      if (grow < N && gcol < M) *(u32x4 *)(C + (size_t)grow * M + gcol) = v;
+    }
+  }
+}
+#undef MM_DMA_PIECE
+
 }  // namespace
 
 bool mfma_i8_serves(const Problem &p) {
@@ -249,8 +412,28 @@ bool mfma_i8_serves(const Problem &p) {
   return !p.a_transposed || (p.n >= 16 && p.n % 16 == 0);
 }
 
+bool mfma_i8_pp_serves(const Problem &p) {
+  return !p.a_transposed && p.k % 64 == 0 && p.k >= 256 && p.m % 16 == 0 && p.m >= 16 && p.n >= 1;
+}
+
+template <int VAR>
+static int launch_i8_pp(hipStream_t s, const Problem &p) {
+  using G = GeoI8PP;
+  const unsigned tiles_n = (p.n + G::BM - 1) / G::BM, tiles_m = (p.m + G::BN - 1) / G::BN;
+  static unsigned long long configured = 0;
+  if (int e = ensure_dynamic_lds((const void *)mfma_i8_pp_kernel<VAR>, G::LDS_BYTES, configured)) return e;
+  hipLaunchKernelGGL((mfma_i8_pp_kernel<VAR>), dim3(tiles_n * tiles_m), dim3(G::THREADS), G::LDS_BYTES, s,
+                     (const signed char *)p.a, (const signed char *)p.b, (signed char *)p.c, p.n, p.k, p.m, tiles_n, tiles_m,
+                     band_rows());
+  return (int)hipGetLastError();
+}
+
 int launch_mfma_i8(hipStream_t s, const Problem &p) {
   if (!mfma_i8_serves(p)) return kErrNotSupported;
+  // i8_variant knob: 0 = one-slab-per-barrier kernel, 10 = ping-pong, 12 = ping-pong in lock step
+  // (ablation); default: ping-pong wherever the shape allows it
+  const int v = tuning(TUNE_I8_VARIANT);
+  if (mfma_i8_pp_serves(p) && v != 0) return v == 12 ? launch_i8_pp<2>(s, p) : launch_i8_pp<0>(s, p);
   using G = GeoI8;
   const unsigned tiles_n = (p.n + G::BM - 1) / G::BM, tiles_m = (p.m + G::BN - 1) / G::BN;
   static unsigned long long configured = 0, configured_at = 0;

@@ -182,6 +182,23 @@ def test_i8_mfma_is_bit_exact_mod_256(dtype, shape):
         assert np.array_equal(c, _oracle.naive(dtype, "Multiply", "Add", aa, bb))
 
 
+@pytest.mark.parametrize("dtype", ["int8_t", "uint8_t"])
+@pytest.mark.parametrize("variant", [-1, 0, 12])
+@pytest.mark.parametrize("shape", [(513, 576, 528), (300, 4160, 272), (257, 256, 1040), (1024, 1024, 1024), (1, 320, 16)],
+                         ids=lambda s: "x".join(map(str, s)))
+def test_i8_mfma_every_schedule_is_bit_exact(dtype, variant, shape):
+    """K % 64 == 0 shapes take the ping-pong schedule by default (-1); 0 = the one-slab-per-barrier
+    kernel, 12 = ping-pong in lock step.  All bit-identical to Naive on full-range bytes."""
+    n, k, m = shape
+    rng = np.random.default_rng(n * 3 + k)
+    a = rng.integers(0, 256, size=(n, k), dtype=np.uint8).view(_oracle.NP_DTYPES[dtype])
+    b = rng.integers(0, 256, size=(k, m), dtype=np.uint8).view(_oracle.NP_DTYPES[dtype])
+    g.set_tuning("i8_variant", variant)
+    c, _ = g.matmul_capi(a, b, dtype)
+    g.set_tuning("i8_variant", -1)
+    assert np.array_equal(c, _oracle.naive(dtype, "Multiply", "Add", a, b))
+
+
 def test_f16_overflow_behaviour_matches_ieee():
     # K large enough that sums pass 65504: binary16 result is +inf, like a correctly rounded result
     n, k, m = 33, 4096, 64

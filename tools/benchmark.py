@@ -3,9 +3,10 @@
 `extract_benchmarks` (:578-669): run `RunHardware*.exe N K M hw off` `repetitions` times per
 configuration, parse `([\\d\\.]+) seconds[^\\d]+([\\d\\.]+) GOp/s`, append rows to benchmark.csv.
 The FPGA columns (tile sizes, frequency, resources) are replaced by what identifies a GPU
-configuration: data type, map/reduce op, sizes, kernel name.  Power (the reference's PSU meter,
-host/RunHardware.cpp:156-185) is sampled from `rocm-smi --showpower` around each run when
-available, otherwise left empty.
+configuration: data type, map/reduce op, sizes, kernel name.  Power: the MM_POWER_METER builds of
+the runner (bin/RunHardware_<cfg>_power.exe) sample the GPU's sensor WHILE the kernel runs and print
+the reference's "Measured an average power of ... W" line (host/RunHardware.cpp:182-185), which is
+parsed with the reference's own second regex (scripts/build_manager.py:603-604).
 
   python tools/benchmark.py [--repetitions 3] [--configs baseline] [--out benchmark.csv]
 """
@@ -18,6 +19,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PERF = re.compile(r"([\d\.]+) seconds[^\d]+([\d\.]+) GOp/s")
+POWER = re.compile(r"([\d\.]+) W")  # scripts/build_manager.py:603-604
 KERNEL = re.compile(r"Executing kernel \(([^)]+)\)")
 BASELINE_CONFIGS = [  # BASELINE.json configs that fit one GPU
     ("float", "Multiply", "Add", 16384, 16384, 16384),
@@ -26,15 +28,6 @@ BASELINE_CONFIGS = [  # BASELINE.json configs that fit one GPU
     ("float", "Add", "Min", 8192, 8192, 8192),
 ]
 QUICK_CONFIGS = [(t, m, r, 2048, 2048, 2048) for (t, m, r, *_rest) in BASELINE_CONFIGS]
-
-
-def power_watts():
-    try:
-        out = subprocess.run(["rocm-smi", "--showpower"], capture_output=True, text=True, timeout=10).stdout
-        m = re.search(r"Power \(W\):\s*([\d\.]+)", out)
-        return float(m.group(1)) if m else None
-    except Exception:
-        return None
 
 
 def main():
@@ -50,7 +43,7 @@ def main():
         w.writerow(["data_type", "map_op", "reduce_op", "size_n", "size_k", "size_m", "kernel", "time", "performance",
                     "power", "power_efficiency"])
         for (dt, mp, rd, n, k, m) in configs:
-            exe = os.path.join(ROOT, "bin", f"RunHardware_{dt}_{mp}_{rd}.exe")
+            exe = os.path.join(ROOT, "bin", f"RunHardware_{dt}_{mp}_{rd}_power.exe")
             done = timeouts = 0
             while done < args.repetitions:
                 print(f"Running {dt} {mp}/{rd} {n}x{k}x{m}, iteration {done + 1} / {args.repetitions}...", flush=True)
@@ -67,7 +60,9 @@ def main():
                     raise SystemExit(f"{exe}: kernel execution failed.\n{r.stdout}{r.stderr}")
                 mt = PERF.search(r.stdout)
                 kn = KERNEL.search(r.stdout)
-                watts = power_watts()
+                pl = [ln for ln in r.stdout.splitlines() if ln.startswith("Measured an average power of")]
+                pm = POWER.search(pl[0]) if pl else None
+                watts = float(pm.group(1)) if pm and float(pm.group(1)) > 0 else None
                 w.writerow([dt, mp, rd, n, k, m, kn.group(1) if kn else "", mt.group(1), mt.group(2),
                             "" if watts is None else watts,
                             "" if watts is None else float(mt.group(2)) / watts])
