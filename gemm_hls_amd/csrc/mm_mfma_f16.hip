@@ -496,6 +496,195 @@ __global__ __launch_bounds__(GeoPP::THREADS) void mfma_f16_pp_kernel(const _Floa
     }
   }
 }
+
+// -------------------------------------------------------------------------------------------------
+// Ping-pong kernel, full-line A requests ("pp2").  Same schedule as above; the difference is how A
+// travels.  A 32-deep slab gives A rows of 64 bytes, i.e. TWO L2 requests per 128-byte line (one per
+// slab); measured: 817 M vs 546 M L2 requests per 16384^3 launch at identical misses, on a kernel
+// whose power budget goes into exactly that path.  Here A is staged in DOUBLE slabs
+// [256 rows][64 k] (128-byte rows, one request per line, chunk index ^ (row>>1)&7), each double slab
+// serving two consecutive segments; B stays in 32-deep slabs.  LDS: 3 A double slabs (96 KiB) +
+// 4 B slabs (64 KiB) = all 160 KiB.  A wave still issues 4 DMA pieces per load segment: 2 of A
+// (its half of double slab u/2 + 2) and 2 of B (slab u + 3); the counted vmcnt(8) and the barrier
+// pairing are unchanged.  Requirements: K % 64 == 0, K >= 256.
+struct GeoPP2 {
+  static constexpr int BM = 256, BN = 256, BK = 32, THREADS = 512;
+  static constexpr int TM = 4, TN = 2;
+  static constexpr int A2_BYTES = BM * 64 * 2, NA = 3;          // A double slab: 32 KiB, ring of 3
+  static constexpr int B_BYTES = BK * BN * 2, NB = 4;           // B slab: 16 KiB, ring of 4
+  static constexpr int B_REGION = NA * A2_BYTES;
+  static constexpr int LDS_BYTES = NA * A2_BYTES + NB * B_BYTES;  // 163840 = the whole LDS of a CU
+  static constexpr int BROW = BN * 2;
+};
+
+template <int VAR>  // bit 1: lock-step ablation
+__global__ __launch_bounds__(GeoPP2::THREADS) void mfma_f16_pp2_kernel(const _Float16 *__restrict__ A,
+                                                                         const _Float16 *__restrict__ B,
+                                                                         _Float16 *__restrict__ C, unsigned N, unsigned K,
+                                                                         unsigned M, unsigned tiles_n, unsigned tiles_m,
+                                                                         unsigned kBand) {
+  using G = GeoPP2;
+  constexpr int TM = G::TM, TN = G::TN;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const unsigned lane = threadIdx.x & 63u;
+  const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const unsigned group = wave >> 2, wq = wave & 3u;
+  const unsigned wm = wq >> 1, wn = (wq & 1u) * 2 + group;
+  const unsigned lo = lane & 31u, hi = lane >> 5;
+
+  const unsigned lin = xcd_remap(blockIdx.x, tiles_n * tiles_m);
+  const unsigned band = lin / (kBand * tiles_m), within = lin % (kBand * tiles_m);
+  const unsigned rows_in_band = min(kBand, tiles_n - band * kBand);
+  const unsigned row0 = (band * kBand + within % rows_in_band) * G::BM, col0 = (within / rows_in_band) * G::BN;
+
+  // ---- DMA offsets: A double slab = 32 pieces of 8 rows x 128 B (4 per wave), B slab = 16 pieces of 2 k-rows
+  unsigned voff_a[4], voff_b[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const unsigned row = (wave + 8 * i) * 8 + lane / 8, pc = lane % 8;
+    voff_a[i] = (min(row0 + row, N - 1) - row0) * K * 2 + (pc ^ ((row >> 1) & 7u)) * 16;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const unsigned kr = (wave + 8 * i) * 2 + lane / 32, pb = lane % 32;
+    const unsigned lc = pb ^ ((kr & 3u) << 2);
+    voff_b[i] = kr * M * 2 + (min(col0 + lc * 8, M - 8) - col0) * 2;
+  }
+  const char *a_base = (const char *)A + (size_t)row0 * K * 2;
+  const char *b_base = (const char *)B + (size_t)col0 * 2;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
+  const unsigned U = K / G::BK, UD = U / 2;
+  // half `h` (pieces wave+16h, wave+16h+8) of A double slab `ds` into A buffer `abuf`, and B slab `slab` into B buffer `bbuf`
+  auto issue_a = [&](unsigned ds, unsigned abuf, int h) {
+    const char *ap = a_base + (size_t)min(ds, UD - 1) * 128;
+    const unsigned la0 = lds0 + abuf * G::A2_BYTES + (wave + 16 * h) * 1024, la1 = la0 + 8 * 1024;
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\t" MM_DMA_PIECE("%1", "%3", "%4") MM_DMA_PIECE("%2", "%3", "%5") "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(h ? voff_a[2] : voff_a[0]), "v"(h ? voff_a[3] : voff_a[1]), "s"(ap), "s"(la0), "s"(la1)
+                 : "memory");
+  };
+  auto issue_b = [&](unsigned slab, unsigned bbuf) {
+    const char *bp = b_base + (size_t)min(slab, U - 1) * G::BK * M * 2;
+    const unsigned lb0 = lds0 + G::B_REGION + bbuf * G::B_BYTES + wave * 1024, lb1 = lb0 + 8 * 1024;
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\t" MM_DMA_PIECE("%1", "%3", "%4") MM_DMA_PIECE("%2", "%3", "%5") "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff_b[0]), "v"(voff_b[1]), "s"(bp), "s"(lb0), "s"(lb1)
+                 : "memory");
+  };
+
+  // ---- fragment addresses.  A: row = wm*128 + mi*32 + lo, logical chunk = 4*h + 2*ks + hi (h = slab parity),
+  //      physical = logical ^ ((lo>>1)&7) = (4h | 2ks) ^ c with c = hi ^ ((lo>>1)&7)
+  const unsigned ca = hi ^ ((lo >> 1) & 7u);
+  const unsigned a_row_byte = (wm * 128 + lo) * 128;
+  unsigned a_off[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) a_off[j] = a_row_byte + ((unsigned)(2 * j) ^ ca) * 16;  // j = 2h + ks
+  const unsigned x = lane & 15u, gq = (lane >> 4) & 1u, r = x >> 2;
+  unsigned b_off[TN];
+#pragma unroll
+  for (int ni = 0; ni < TN; ++ni) {
+    const unsigned logical = wn * 8 + ni * 4 + 2 * gq + ((x & 3u) >> 1);
+    b_off[ni] = G::B_REGION + (8 * hi + r) * G::BROW + (logical ^ (r << 2)) * 16 + (x & 1u) * 8;
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni) acc[mi][ni] = (f32x16)0.0f;
+
+  auto sync = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // one slab u: BUF = u % 4 (B buffer, compile time), abuf = (u/2) % 3 (A buffer of the double slab being read)
+  auto phase = [&](auto bufc, unsigned u, unsigned abuf) {
+    constexpr int BUF = decltype(bufc)::value;
+    constexpr int H = BUF & 1;
+    const char *abase = smem + abuf * G::A2_BYTES;
+    const char *bbase = smem + BUF * G::B_BYTES;
+    h8 af[TM][2], bf[TN][2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int ni = 0; ni < TN; ++ni) {
+        const char *p = bbase + b_off[ni] + ks * 16 * G::BROW;
+        const s4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s4 __attribute__((address_space(3))) *)(lptr_t)p);
+        const s4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s4 __attribute__((address_space(3))) *)(lptr_t)(p + 4 * G::BROW));
+        bf[ni][ks] = join(v0, v1);
+      }
+#pragma unroll
+      for (int mi = 0; mi < TM; ++mi) af[mi][ks] = *(const h8 *)(abase + a_off[2 * H + ks] + mi * 32 * 128);
+    }
+    const unsigned abuf_fill = abuf >= 1 ? abuf - 1 : 2;           // (abuf + 2) % 3: the buffer of double slab u/2 - 1
+    issue_a(u / 2 + 2, abuf_fill, H);
+    issue_b(u + 3, (BUF + 3) & 3);
+    asm volatile("s_waitcnt vmcnt(8)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+    sync();
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mi][ks], bf[ni][ks], acc[mi][ni], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    sync();
+  };
+
+  // ---- prologue = the issue order of virtual segments -4 .. -1, so that the steady-state vmcnt(8)
+  //      ("everything issued two segments ago has landed") holds from the first segment on
+  issue_a(0, 0, 0);
+  issue_a(0, 0, 1);
+  issue_b(0, 0);
+  issue_a(1, 1, 0);
+  issue_b(1, 1);
+  issue_a(1, 1, 1);
+  issue_b(2, 2);
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  sync();
+  const bool shifted = !(VAR & 2) && group == 1;
+  if (shifted) sync();
+  unsigned ab = 0;  // (u / 2) % 3 at the top of the 4-slab body
+  for (unsigned u = 0; u < U; u += 4) {
+    const unsigned ab1 = ab == 2 ? 0 : ab + 1;
+    phase(std::integral_constant<int, 0>{}, u, ab);
+    phase(std::integral_constant<int, 1>{}, u + 1, ab);
+    if (u + 2 < U) {                                            // U is even: slabs come in pairs
+      phase(std::integral_constant<int, 2>{}, u + 2, ab1);
+      phase(std::integral_constant<int, 3>{}, u + 3, ab1);
+    }
+    ab = ab1 == 2 ? 0 : ab1 + 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (!shifted && !(VAR & 2)) sync();
+  sync();
+
+  {
+    char *slice = smem + wave * (128 * 128);
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+          const unsigned row = mi * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * hi;
+          *(_Float16 *)(slice + row * 128 + (ni * 32 + lo) * 2) = (_Float16)acc[mi][ni][rr];
+        }
+    using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+#pragma unroll
+    for (int it = 0; it < 128 * 8 / 64; ++it) {
+      const unsigned c = it * 64 + lane, row = c / 8, ch = c % 8;
+      const u32x4 v = *(const u32x4 *)(slice + row * 128 + ch * 16);
+      const unsigned grow = row0 + wm * 128 + row, gcol = col0 + wn * 64 + ch * 8;
+      if (grow < N && gcol < M) *(u32x4 *)(C + (size_t)grow * M + gcol) = v;
+    }
+  }
+}
 #undef MM_DMA_PIECE
 
 }  // namespace
@@ -530,6 +719,19 @@ static int launch_pp(hipStream_t s, const Problem &p) {
   return (int)hipGetLastError();
 }
 
+bool mfma_f16_pp2_serves(const Problem &p) { return mfma_f16_pp_serves(p) && p.k % 64 == 0 && p.k >= 256; }
+
+template <int VAR>
+static int launch_pp2(hipStream_t s, const Problem &p) {
+  using G = GeoPP2;
+  const unsigned tiles_n = (p.n + G::BM - 1) / G::BM, tiles_m = (p.m + G::BN - 1) / G::BN;
+  static unsigned long long configured = 0;
+  if (int e = ensure_dynamic_lds((const void *)mfma_f16_pp2_kernel<VAR>, G::LDS_BYTES, configured)) return e;
+  hipLaunchKernelGGL((mfma_f16_pp2_kernel<VAR>), dim3(tiles_n * tiles_m), dim3(G::THREADS), G::LDS_BYTES, s,
+                     (const _Float16 *)p.a, (const _Float16 *)p.b, (_Float16 *)p.c, p.n, p.k, p.m, tiles_n, tiles_m, band_rows());
+  return (int)hipGetLastError();
+}
+
 int mfma_f16_tile(const Problem &p) {  // 0: 256x256, 4: 128x256
   static const TileCandidate cands[] = {{0, 256, 256, 1, 1.00}, {4, 128, 256, 1, 0.80}};
   return p.a_transposed ? 0 : pick_tile(cands, 2, p.n, p.m);
@@ -539,7 +741,9 @@ int launch_mfma_f16(hipStream_t s, const Problem &p) {
   if (!mfma_f16_serves(p)) return kErrNotSupported;
   if (p.a_transposed) return launch_h<GeoH, true>(s, p);
   const int v = tuning(TUNE_F16_VARIANT);  // tuning hook
-  if (v >= 10 && mfma_f16_pp_serves(p)) {  // 10 + VAR of the ping-pong kernel
+  if (v == 100 && mfma_f16_pp2_serves(p)) return launch_pp2<0>(s, p);  // full-line A requests
+  if (v == 102 && mfma_f16_pp2_serves(p)) return launch_pp2<2>(s, p);  //   ... in lock step (ablation)
+  if (v >= 10 && v < 100 && mfma_f16_pp_serves(p)) {  // 10 + VAR of the ping-pong kernel
     switch (v - 10) {
       case 0: return launch_pp<0>(s, p);
       case 1: return launch_pp<1>(s, p);
@@ -564,6 +768,7 @@ int launch_mfma_f16(hipStream_t s, const Problem &p) {
   // default: the shape-adaptive tile pick; where that is the 256 x 256 tile and the shape allows it,
   // the ping-pong schedule (84-89 % MFMA utilisation vs 67 %, profiles/r02d_pmc_f16_32768_v*.json)
   if (mfma_f16_tile(p) == 4) return launch_h<GeoHS>(s, p);
+  if (mfma_f16_pp2_serves(p)) return launch_pp2<0>(s, p);  // +2-4 % over pp: one L2 request per A line (profiles/r02h_*)
   if (mfma_f16_pp_serves(p)) return launch_pp<1>(s, p);
   return launch_h<GeoH>(s, p);
 }

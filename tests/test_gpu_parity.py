@@ -122,12 +122,13 @@ def test_f16_mfma_wide_accumulate_contract(shape):
     assert rel.max() <= 2.0 ** -11 * 1.01      # half an ulp of binary16 relative to the exact value (+f32 noise)
 
 
-@pytest.mark.parametrize("variant", [10, 11, 12, 13, 14, 15, 19, 23, 0, 1, 4])
+@pytest.mark.parametrize("variant", [10, 11, 12, 13, 14, 15, 19, 23, 100, 102, 0, 1, 4])
 @pytest.mark.parametrize("shape", [(513, 544, 528), (300, 128, 272), (257, 1056, 520), (1024, 4096, 1024), (129, 160, 264),
-                                   (770, 2048, 1288)], ids=lambda s: "x".join(map(str, s)))
+                                   (770, 2048, 1288), (300, 256, 272), (513, 576, 528), (260, 320, 264)],
+                         ids=lambda s: "x".join(map(str, s)))
 def test_f16_mfma_every_variant(variant, shape):
     """Every schedule of the half kernel (10-13: ping-pong with / without priority and the lock-step
-    ablation; 0, 1, 4: the one-slab-per-barrier geometries) against the wide-accumulate oracle, and
+    ablation; 100 / 102: ping-pong with full-line A requests; 0, 1, 4: the one-slab-per-barrier geometries) against the wide-accumulate oracle, and
     all of them against each other: same products, fp32 accumulation in k order per 16-deep MFMA."""
     n, k, m = shape
     rng = np.random.default_rng(n + k)
@@ -183,12 +184,14 @@ def test_i8_mfma_is_bit_exact_mod_256(dtype, shape):
 
 
 @pytest.mark.parametrize("dtype", ["int8_t", "uint8_t"])
-@pytest.mark.parametrize("variant", [-1, 0, 12])
-@pytest.mark.parametrize("shape", [(513, 576, 528), (300, 4160, 272), (257, 256, 1040), (1024, 1024, 1024), (1, 320, 16)],
+@pytest.mark.parametrize("variant", [-1, 0, 10, 12, 100])
+@pytest.mark.parametrize("shape", [(513, 576, 528), (300, 4160, 272), (257, 256, 1040), (1024, 1024, 1024), (1, 320, 16),
+                                   (513, 640, 528), (300, 4224, 272), (260, 512, 1040)],
                          ids=lambda s: "x".join(map(str, s)))
 def test_i8_mfma_every_schedule_is_bit_exact(dtype, variant, shape):
-    """K % 64 == 0 shapes take the ping-pong schedule by default (-1); 0 = the one-slab-per-barrier
-    kernel, 12 = ping-pong in lock step.  All bit-identical to Naive on full-range bytes."""
+    """-1 = the default pick (ping-pong with full-line A requests when K % 128 == 0, plain ping-pong
+    when K % 64 == 0); 0 = the one-slab-per-barrier kernel, 10 / 12 = ping-pong / in lock step,
+    100 = full-line A requests.  All bit-identical to Naive on full-range bytes."""
     n, k, m = shape
     rng = np.random.default_rng(n * 3 + k)
     a = rng.integers(0, 256, size=(n, k), dtype=np.uint8).view(_oracle.NP_DTYPES[dtype])
