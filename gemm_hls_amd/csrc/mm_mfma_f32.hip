@@ -59,8 +59,19 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 typedef const __attribute__((address_space(1))) void *gptr_t;
 typedef __attribute__((address_space(3))) void *lptr_t;
 
-template <int TM_, int WM_, int WN_, int BK_, int NS_, bool TWO_LEVEL_, int KC_, int FC_ = 0>
+template <int TM_, int WM_, int WN_, int BK_, int NS_, bool TWO_LEVEL_, int KC_, int FC_ = 0, bool STAGGER_ = false,
+          bool PIN_ = false>
 struct Geo {
+  // PIN: a scheduling fence after every group's fragment reads.  Without it hipcc sinks four of the six
+  // ds_read_b128 of a k-group down to just before the slab barrier, where the s_waitcnt lgkmcnt(0)
+  // that the barrier needs then exposes their full LDS latency once per slab.
+  static constexpr bool PIN = PIN_;
+  // STAGGER: the second half of the wavefronts (the SIMD partners of the first half) issue their
+  // share of a slab's DMA one k-group later instead of right after the barrier.  An LDS-DMA
+  // instruction blocks its wave's issue for 60-190 cycles; with both waves of a SIMD doing that at the
+  // same moment the matrix pipe idles (the 5-6 % this kernel was missing); staggered, one partner
+  // always has MFMAs to issue.  Needs NS == 2 (the pre-barrier wait is vmcnt(0), whatever the order).
+  static constexpr bool STAGGER = STAGGER_;
   static constexpr int TM = TM_, WM = WM_, WN = WN_, BK = BK_, NS = NS_, KC = KC_;
   static constexpr int FC = FC_;  // > 0: flush the accumulators into C every FC slabs (see below)
   static constexpr bool TWO_LEVEL = TWO_LEVEL_;
@@ -79,6 +90,7 @@ struct Geo {
   static_assert(BK == 16 || BK == 32, "BK");
   static_assert(NA % NW == 0 && NB % NW == 0, "DMA instructions must split evenly over waves");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+  static_assert(!STAGGER || (NS == 2 && BK / 8 >= 2 && NW % 2 == 0), "stagger");
 };
 
 template <typename G, bool AT>
@@ -239,11 +251,22 @@ __global__ __launch_bounds__(G::THREADS) void mfma_f32_kernel(const float *__res
 
   f32x4 af0[TM], bf0[4], af1[TM], bf1[4];
   load_frags(0, 0, af0, bf0);
+  const bool late = G::STAGGER && wave >= G::NW / 2;  // waves w and w + NW/2 share a SIMD
 
   // One full slab that HAS a successor.  8-deep k-groups, register double-buffered fragments
   // (set 0 for even groups, set 1 for odd; KG is even so the alternation carries across slabs).
   // The last group's MFMAs are issued after the barrier that publishes slab t+1 and after that
   // slab's first fragment reads, so barrier skew and LDS latency hide under them.
+  // p-pairs [2h, 2h+1] of a k-group: the two halves of mfma_group, in the same accumulation order
+  auto mfma_half = [&](const f32x4 (&af)[TM], const f32x4 (&bf)[4], int h) {
+#pragma unroll
+    for (int p = 2 * h; p < 2 * h + 2; ++p)
+#pragma unroll
+      for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+        for (int t = 0; t < TN; ++t)
+          acc[mi][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi][p], bf[p][t], acc[mi][t], 0, 0, 0);
+  };
   auto slab = [&](unsigned t) {
     const unsigned buf = t % NS;
 #pragma unroll
@@ -252,7 +275,29 @@ __global__ __launch_bounds__(G::THREADS) void mfma_f32_kernel(const float *__res
       f32x4(&bfc)[4] = (kg & 1) ? bf1 : bf0;
       f32x4(&afn)[TM] = (kg & 1) ? af0 : af1;
       f32x4(&bfn)[4] = (kg & 1) ? bf0 : bf1;
+      if (G::PIN) {
+        // Pinned order: [barrier, DMA] | first half of this group's MFMAs | the NEXT group's fragment
+        // reads | second half.  The compiler's wait for a group's fragments then always sits behind
+        // 16 MFMAs (1024 cycles) of cover instead of right behind the reads.
+        if (kg + 1 == G::KG) {
+          asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NS - 2) * L) : "memory");
+          __builtin_amdgcn_s_barrier();
+          if (!G::STAGGER || !late) stage(buf, (t + NS) * BK);
+        } else if (G::STAGGER && kg == 0 && late && t > 0) {
+          stage((t - 1) % NS, (t - 1 + NS) * BK);  // the refill the early half issued a k-group ago
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_half(afc, bfc, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kg + 1 < G::KG) load_frags(buf, kg + 1, afn, bfn);
+        else load_frags((t + 1) % NS, 0, afn, bfn);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_half(afc, bfc, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        continue;
+      }
       if (kg + 1 < G::KG) {
+        if (G::STAGGER && kg == 0 && late && t > 0) stage((t - 1) % NS, (t - 1 + NS) * BK);  // the refill E issued a k-group ago
         load_frags(buf, kg + 1, afn, bfn);
       } else {
         // Slab t+1 must have landed; slabs t+2 .. t+NS-1 may stay in flight across the barrier.
@@ -260,7 +305,7 @@ __global__ __launch_bounds__(G::THREADS) void mfma_f32_kernel(const float *__res
         // barrier its ring slot is free for slab t+NS.
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NS - 2) * L) : "memory");
         __builtin_amdgcn_s_barrier();
-        stage(buf, (t + NS) * BK);
+        if (!G::STAGGER || !late) stage(buf, (t + NS) * BK);
         load_frags((t + 1) % NS, 0, afn, bfn);
       }
       mfma_group(afc, bfc);
@@ -377,10 +422,14 @@ using V12 = Geo<2, 4, 2, 16, 4, false, 1, 256>; // V8 with a 4-slab ring (128 Ki
 using V13 = Geo<2, 2, 2, 32, 2, false, 1, 128>; // 128x256x32, 4 waves, flush every 4096 k (mid-size shapes)
 using V14 = Geo<1, 4, 1, 32, 2, false, 1, 128>; // 128x128x32, 4 waves of 32x128, 64 KiB LDS: 2 workgroups per CU (small shapes)
 using V15 = Geo<2, 2, 2, 16, 2, false, 1, 256>; // 128x256x16, 4 waves, 48 KiB LDS: 2 independent workgroups per CU
+using V16 = Geo<2, 4, 2, 16, 2, false, 1, 256, true>;  // V8 + staggered DMA issue between SIMD partners
+using V17 = Geo<2, 4, 2, 32, 2, false, 1, 128, true>;  // V10 (256x256x32) + stagger
+using V18 = Geo<2, 4, 2, 16, 2, false, 1, 256, false, true>;  // V8 + pinned fragment reads
+using V19 = Geo<2, 4, 2, 16, 2, false, 1, 256, true, true>;   // V8 + stagger + pinned fragment reads
 
 }  // namespace
 
-int mfma_f32_num_variants() { return 16; }
+int mfma_f32_num_variants() { return 20; }
 
 const char *mfma_f32_name(int v) {
   switch (v) {
@@ -400,6 +449,10 @@ const char *mfma_f32_name(int v) {
     case 13: return "mfma_f32_128x256x32_w4_flush4096";
     case 14: return "mfma_f32_128x128x32_w4_flush4096";
     case 15: return "mfma_f32_128x256x16_w4_flush4096_2percu";
+    case 16: return "mfma_f32_256x256x16_w8_flush4096_stagger";
+    case 17: return "mfma_f32_256x256x32_w8_flush4096_stagger";
+    case 18: return "mfma_f32_256x256x16_w8_flush4096_pin";
+    case 19: return "mfma_f32_256x256x16_w8_flush4096_stagger_pin";
   }
   return "?";
 }
@@ -424,6 +477,10 @@ void mfma_f32_geometry(int v, unsigned *bm, unsigned *bn, unsigned *bk, unsigned
     case 13: return geo_of<V13>(bm, bn, bk, waves);
     case 14: return geo_of<V14>(bm, bn, bk, waves);
     case 15: return geo_of<V15>(bm, bn, bk, waves);
+    case 16: return geo_of<V16>(bm, bn, bk, waves);
+    case 17: return geo_of<V17>(bm, bn, bk, waves);
+    case 18: return geo_of<V18>(bm, bn, bk, waves);
+    case 19: return geo_of<V19>(bm, bn, bk, waves);
     default: return geo_of<V8>(bm, bn, bk, waves);
   }
 }
@@ -464,6 +521,10 @@ int launch_mfma_f32(hipStream_t s, const Problem &p, int variant) {
     case 13: return launch_geo<V13>(s, p);
     case 14: return launch_geo<V14>(s, p);
     case 15: return launch_geo<V15>(s, p);
+    case 16: return launch_geo<V16>(s, p);
+    case 17: return launch_geo<V17>(s, p);
+    case 18: return launch_geo<V18>(s, p);
+    case 19: return launch_geo<V19>(s, p);
   }
   return kErrNotSupported;
 }
