@@ -122,6 +122,7 @@ enum Tunable {
   TUNE_F16_VARIANT,      // MM_F16_VARIANT
   TUNE_I8_VARIANT,       // MM_I8_VARIANT
   TUNE_BAND_ROWS,        // MM_BAND_ROWS    tile-rows per rasterisation band
+  TUNE_VALU_VARIANT,     // MM_VALU_VARIANT 0 = synchronous valu_tile kernel, else (default) the DMA-staged one
   TUNE_COUNT
 };
 int tuning(Tunable t);  // mm_capi.hip

@@ -27,10 +27,10 @@ SHAPES = [(513, 528, 528), (1, 16, 16), (37, 32, 48), (300, 64, 272), (129, 80, 
 @pytest.fixture(autouse=True)
 def _default_tuning():
     """Every test starts and ends on the library's own geometry choice (knobs are process-wide)."""
-    for knob in ("f32_variant", "f64_variant", "f16_variant", "i8_variant", "band_rows"):
+    for knob in ("f32_variant", "f64_variant", "f16_variant", "i8_variant", "band_rows", "valu_variant"):
         g.set_tuning(knob, -1)
     yield
-    for knob in ("f32_variant", "f64_variant", "f16_variant", "i8_variant", "band_rows"):
+    for knob in ("f32_variant", "f64_variant", "f16_variant", "i8_variant", "band_rows", "valu_variant"):
         g.set_tuning(knob, -1)
 
 
@@ -256,6 +256,29 @@ def test_auto_path_exact_semirings(dtype, mp, rd, shape):
     a, b = _oracle.fill(dtype, n, k, m)
     c, _ = g.matmul_capi(a, b, dtype, mp, rd)
     assert np.array_equal(c, _oracle.naive(dtype, mp, rd, a, b))
+
+
+@pytest.mark.parametrize("dtype,mp,rd", [("float", "Add", "Min"), ("float", "Add", "Max"), ("float", "Min", "Max"),
+                                          ("int", "Multiply", "Add"), ("unsigned", "Add", "Min"), ("int", "Max", "Min")],
+                         ids=lambda x: str(x))
+@pytest.mark.parametrize("shape", [(513, 528, 528), (129, 20, 260), (300, 36, 132), (257, 600, 516), (1, 16, 4), (700, 8, 64),
+                                   (130, 1028, 128)], ids=lambda s: "x".join(map(str, s)))
+def test_valu_tile_dma_staged_kernel_equals_synchronous_kernel_and_naive(dtype, mp, rd, shape):
+    """4-byte types, row-major A: the default VALU kernel stages through LDS-DMA (double-buffered, the
+    last partial slab fetched as the last 16 k of the matrix); valu_variant 0 is the synchronous one.
+    Same per-output operation sequence -> same bits, and both equal Naive for these semirings."""
+    n, k, m = shape
+    a, b = _oracle.fill(dtype, n, k, m)
+    if dtype == "float":   # signs and magnitudes beyond the generator's [1,10)
+        rng = np.random.default_rng(n + k + m)
+        a = (a * rng.choice([-1.0, 1.0], size=a.shape)).astype(np.float32)
+        b = (b - 5.5).astype(np.float32)
+    want = _oracle.naive(dtype, mp, rd, a, b)
+    for variant in (-1, 0):
+        g.set_tuning("valu_variant", variant)
+        c, _ = g.matmul_capi(a, b, dtype, mp, rd)
+        assert np.array_equal(c.view(np.uint8), want.view(np.uint8)), (variant, dtype, mp, rd, shape)
+    g.set_tuning("valu_variant", -1)
 
 
 def _golden_cases():

@@ -57,7 +57,7 @@ def main():
     else:
         table = {"f64": ("double", "Multiply", "Add"), "f16": ("half", "Multiply", "Add"),
                  "minplus": ("float", "Add", "Min"), "uint8": ("uint8_t", "Multiply", "Add")}
-        knob = {"f64": "f64_variant", "f16": "f16_variant", "uint8": "i8_variant"}
+        knob = {"f64": "f64_variant", "f16": "f16_variant", "uint8": "i8_variant", "minplus": "valu_variant"}
         for key in ([args.what] if args.what != "all" else list(table)):
             dtype, mp, rd = table[key]
             variants = [int(v) for v in args.variants.split(",")] if (args.variants and key in knob) else [-1]
