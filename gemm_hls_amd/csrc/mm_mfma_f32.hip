@@ -48,6 +48,7 @@
 // the DMA of its unused part is clamped to valid addresses and never read).  Everything else is
 // served by the predicated kernels (mm_valu_tile / mm_ordered).
 #include <cstdlib>
+#include <type_traits>
 
 #include "mm_common.h"
 
@@ -384,6 +385,190 @@ __global__ __launch_bounds__(G::THREADS) void mfma_f32_kernel(const float *__res
   if (G::FC > 0 && flushed) write_tile(true); else write_tile(false);
 }
 
+// =================================================================================================
+// Ping-pong schedule for fp32 (round 2) -- the structure that took the half kernel from 67 % to 90 %
+// MFMA utilisation (mm_mfma_f16.hip), with this file's fragment trick:
+//   256 x 256 tile, 8 waves of 64 x 128 (2 x 4 accumulators), 16-deep slabs in a 4-slab LDS ring
+//   (4 x 32 KiB), 3 slabs in flight; waves 0-3 and their SIMD partners 4-7 run the same code one
+//   barrier apart: one group issues its 64 MFMAs of slab u (4096 cycles per SIMD) while the other
+//   reads its 12 fragment vectors of its next slab and issues its 4 DMA pieces of slab u + 3.
+//   A slab [256][16] floats: 64-B rows, chunk ^ (row>>2)&3; B slab [16][256] floats as in memory.
+//   DMA: uniform SGPR base + constant per-lane 32-bit offset; counted vmcnt(8); a slab is read one
+//   segment after the barrier that retires it, a buffer refilled only after a barrier every reader
+//   passed with lgkmcnt(0).
+// Accumulation order per output and the flush every 4096 k are those of the default kernel (V8):
+// the two are bit-identical (tests).  Requirements: K % 16 == 0, K >= 64, M % 4 == 0, row-major A.
+// MEASURED SLOWER than the default kernel (143.4 vs 145.7 TF at 16384^3, profiles/r02m_*): with
+// 64-cycle MFMAs the compiler-scheduled one-barrier-per-slab stream already hides its DMA issue and
+// LDS latency; the antiphase buys +1 % over its own lock-step ablation and pays more for the two
+// barriers per slab.  Kept as variants 20 / 21 (tested) for that record; not dispatched by default.
+struct GeoF32PP {
+  static constexpr int BM = 256, BN = 256, BK = 16, THREADS = 512, TM = 2, TN = 4;
+  static constexpr int A_BYTES = BM * BK * 4, B_BYTES = BK * BN * 4, STAGE_BYTES = A_BYTES + B_BYTES;
+  static constexpr int LDS_BYTES = 4 * STAGE_BYTES;  // 128 KiB
+  static constexpr int FLUSH_SLABS = 256;            // 4096 k
+};
+#define MM_DMA_PIECE(vo, sb, la) "s_mov_b32 m0, " la "\n\ts_nop 0\n\tglobal_load_lds_dwordx4 " vo ", " sb "\n\t"
+
+template <int VAR>  // bit 1: lock-step ablation
+__global__ __launch_bounds__(GeoF32PP::THREADS) void mfma_f32_pp_kernel(const float *__restrict__ A,
+                                                                         const float *__restrict__ B,
+                                                                         float *__restrict__ C, unsigned N, unsigned K,
+                                                                         unsigned M, unsigned tiles_n, unsigned tiles_m,
+                                                                         unsigned kBand) {
+  using G = GeoF32PP;
+  constexpr int TM = G::TM, TN = G::TN;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const unsigned lane = threadIdx.x & 63u;
+  const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const unsigned group = wave >> 2, wq = wave & 3u;       // waves w and w + 4 share a SIMD
+  const unsigned wm = wq, wn = group;                      // 4 x 2 wave grid of 64 x 128 blocks
+  const unsigned lo = lane & 31u, hi = lane >> 5;
+
+  const unsigned lin = xcd_remap(blockIdx.x, tiles_n * tiles_m);
+  const unsigned band = lin / (kBand * tiles_m), within = lin % (kBand * tiles_m);
+  const unsigned rows_in_band = min(kBand, tiles_n - band * kBand);
+  const unsigned row0 = (band * kBand + within % rows_in_band) * G::BM, col0 = (within / rows_in_band) * G::BN;
+
+  // DMA: 16 A pieces (16 rows x 64 B) + 16 B pieces (one k-row of 1 KiB) per slab, 2 + 2 per wave
+  unsigned voff_a[2], voff_b[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const unsigned piece = wave + 8 * i;
+    const unsigned row = piece * 16 + lane / 4, pc = lane % 4;
+    voff_a[i] = (min(row0 + row, N - 1) - row0) * K * 4 + (pc ^ ((row >> 2) & 3u)) * 16;
+    voff_b[i] = piece * M * 4 + (min(col0 + lane * 4, M - 4) - col0) * 4;
+  }
+  const char *a_base = (const char *)A + (size_t)row0 * K * 4;
+  const char *b_base = (const char *)B + (size_t)col0 * 4;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
+  const unsigned U = K / G::BK;
+  auto issue = [&](unsigned slab, unsigned buf) {
+    const unsigned sl = min(slab, U - 1);
+    const char *ap = a_base + (size_t)sl * (G::BK * 4);
+    const char *bp = b_base + (size_t)sl * G::BK * M * 4;
+    const unsigned la0 = lds0 + buf * G::STAGE_BYTES + wave * 1024, la1 = la0 + 8 * 1024;
+    const unsigned lb0 = la0 + G::A_BYTES, lb1 = lb0 + 8 * 1024;
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\t" MM_DMA_PIECE("%1", "%5", "%7") MM_DMA_PIECE("%2", "%5", "%8")
+                     MM_DMA_PIECE("%3", "%6", "%9") MM_DMA_PIECE("%4", "%6", "%10") "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff_a[0]), "v"(voff_a[1]), "v"(voff_b[0]), "v"(voff_b[1]), "s"(ap), "s"(bp), "s"(la0), "s"(la1),
+                   "s"(lb0), "s"(lb1)
+                 : "memory");
+  };
+
+  // fragments.  A: row = wm*64 + mi*32 + lo, logical chunk = 2*kg + hi, physical = (2*kg) ^ (hi ^ (lo>>2)&3)
+  const unsigned ca = hi ^ ((lo >> 2) & 3u);
+  const unsigned a_row_byte = (wm * 64 + lo) * (G::BK * 4);
+  const unsigned a_off[2] = {a_row_byte + ca * 16, a_row_byte + (ca ^ 2u) * 16};
+  // B: k = kg*8 + p + 4*hi, 4 consecutive columns wn*128 + 4*lo
+  const unsigned b_off = G::A_BYTES + (4 * hi) * (G::BN * 4) + (wn * 128 + 4 * lo) * 4;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+    for (int t = 0; t < TN; ++t) acc[mi][t] = (f32x16)0.0f;
+
+  auto sync = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // C (+)= accumulators (lane owns 4 consecutive columns of 16 rows per row block); optionally restart them
+  auto write_tile = [&](bool accumulate, bool restart) {
+    const unsigned ccol = col0 + wn * 128 + 4 * lo;
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const unsigned row = row0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        if (ccol < M && row < N) {
+          f32x4 *dst = (f32x4 *)(C + (size_t)row * M + ccol);
+          f32x4 v;
+#pragma unroll
+          for (int t = 0; t < TN; ++t) v[t] = acc[mi][t][r];
+          if (accumulate) v += *dst;
+          *dst = v;
+        }
+      }
+      if (restart) {
+#pragma unroll
+        for (int t = 0; t < TN; ++t) acc[mi][t] = (f32x16)0.0f;
+      }
+    }
+  };
+  bool flushed = false;
+  auto phase = [&](auto bufc, unsigned u) {
+    constexpr int BUF = decltype(bufc)::value;
+    const char *base = smem + BUF * G::STAGE_BYTES;
+    f32x4 af[2][TM], bf[2][4];
+#pragma unroll
+    for (int kg = 0; kg < 2; ++kg) {
+#pragma unroll
+      for (int p = 0; p < 4; ++p) bf[kg][p] = *(const f32x4 *)(base + b_off + (kg * 8 + p) * (G::BN * 4));
+#pragma unroll
+      for (int mi = 0; mi < TM; ++mi) af[kg][mi] = *(const f32x4 *)(base + a_off[kg] + mi * 32 * (G::BK * 4));
+    }
+    issue(u + 3, (BUF + 3) & 3);
+    asm volatile("s_waitcnt vmcnt(8)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+    sync();
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kg = 0; kg < 2; ++kg)
+#pragma unroll
+      for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+          for (int t = 0; t < TN; ++t)
+            acc[mi][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kg][mi][p], bf[kg][p][t], acc[mi][t], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    // bound the summation chain: every 4096 k this wave adds its accumulators into its own part of C
+    // and restarts them (private to the wave: no barrier involved, the partner keeps the pipe busy)
+    if ((u + 1) % G::FLUSH_SLABS == 0 && u + 2 < U) {  // same flush points as the default kernel (none before the last slab)
+      write_tile(flushed, true);
+      flushed = true;
+    }
+    sync();
+  };
+
+  issue(0, 0);
+  issue(1, 1);
+  issue(2, 2);
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  sync();
+  const bool shifted = !(VAR & 2) && group == 1;
+  if (shifted) sync();
+  for (unsigned u = 0; u < U; u += 4) {
+    phase(std::integral_constant<int, 0>{}, u);
+    if (u + 1 < U) phase(std::integral_constant<int, 1>{}, u + 1);
+    if (u + 2 < U) phase(std::integral_constant<int, 2>{}, u + 2);
+    if (u + 3 < U) phase(std::integral_constant<int, 3>{}, u + 3);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (!shifted && !(VAR & 2)) sync();
+  sync();
+  write_tile(flushed, false);
+}
+#undef MM_DMA_PIECE
+
+bool mfma_f32_pp_serves_impl(const Problem &p) {
+  return !p.a_transposed && p.k % 16 == 0 && p.k >= 64 && p.m % 4 == 0 && p.m >= 4 && p.n >= 1;
+}
+
+template <int VAR>
+int launch_f32_pp(hipStream_t s, const Problem &p) {
+  using G = GeoF32PP;
+  const unsigned tiles_n = (p.n + G::BM - 1) / G::BM, tiles_m = (p.m + G::BN - 1) / G::BN;
+  static unsigned long long configured = 0;
+  if (int e = ensure_dynamic_lds((const void *)mfma_f32_pp_kernel<VAR>, G::LDS_BYTES, configured)) return e;
+  hipLaunchKernelGGL((mfma_f32_pp_kernel<VAR>), dim3(tiles_n * tiles_m), dim3(G::THREADS), G::LDS_BYTES, s,
+                     (const float *)p.a, (const float *)p.b, (float *)p.c, p.n, p.k, p.m, tiles_n, tiles_m, band_rows());
+  return (int)hipGetLastError();
+}
+
 template <typename G>
 int launch_geo(hipStream_t s, const Problem &p) {
   const unsigned tiles_n = (p.n + G::BM - 1) / G::BM, tiles_m = (p.m + G::BN - 1) / G::BN;
@@ -429,7 +614,7 @@ using V19 = Geo<2, 4, 2, 16, 2, false, 1, 256, true, true>;   // V8 + stagger + 
 
 }  // namespace
 
-int mfma_f32_num_variants() { return 20; }
+int mfma_f32_num_variants() { return 22; }
 
 const char *mfma_f32_name(int v) {
   switch (v) {
@@ -453,6 +638,8 @@ const char *mfma_f32_name(int v) {
     case 17: return "mfma_f32_256x256x32_w8_flush4096_stagger";
     case 18: return "mfma_f32_256x256x16_w8_flush4096_pin";
     case 19: return "mfma_f32_256x256x16_w8_flush4096_stagger_pin";
+    case 20: return "mfma_f32_256x256x16_w8_flush4096_pingpong";
+    case 21: return "mfma_f32_256x256x16_w8_flush4096_pingpong_lockstep";
   }
   return "?";
 }
@@ -525,6 +712,8 @@ int launch_mfma_f32(hipStream_t s, const Problem &p, int variant) {
     case 17: return launch_geo<V17>(s, p);
     case 18: return launch_geo<V18>(s, p);
     case 19: return launch_geo<V19>(s, p);
+    case 20: return mfma_f32_pp_serves_impl(p) ? launch_f32_pp<0>(s, p) : launch_geo<V8>(s, p);
+    case 21: return mfma_f32_pp_serves_impl(p) ? launch_f32_pp<2>(s, p) : launch_geo<V8>(s, p);
   }
   return kErrNotSupported;
 }

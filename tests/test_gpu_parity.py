@@ -47,7 +47,7 @@ def test_f32_mfma_default_vs_blas_and_exact(shape):
     assert np.max(np.abs(c - exact) / exact) < F32_TOL
 
 
-@pytest.mark.parametrize("variant", range(20))
+@pytest.mark.parametrize("variant", range(22))
 @pytest.mark.parametrize("shape", [(513, 528, 528), (300, 64, 272), (256, 8, 4), (37, 32, 48), (300, 8208, 272)],
                          ids=lambda s: "x".join(map(str, s)))
 def test_f32_mfma_every_variant(variant, shape):
@@ -58,6 +58,23 @@ def test_f32_mfma_every_variant(variant, shape):
     exact = a.astype(np.float64) @ b.astype(np.float64)
     rel = np.abs(c - exact) / exact
     assert np.max(rel) < F32_TOL, (variant, np.unravel_index(np.argmax(rel), rel.shape), rel.max())
+
+
+@pytest.mark.parametrize("shape", [(1024, 8208, 512), (513, 4112, 528), (300, 64, 272), (257, 12304, 260)],
+                         ids=lambda s: "x".join(map(str, s)))
+def test_f32_pingpong_schedule_is_bit_identical_to_the_default_kernel(shape):
+    """Variant 20 (ping-pong) keeps the default kernel's accumulation order and its flush every 4096 k
+    (two and three flushes in these shapes): identical bits, also with mixed signs."""
+    n, k, m = shape
+    rng = np.random.default_rng(k)
+    a = rng.uniform(-3, 10, size=(n, k)).astype(np.float32)
+    b = rng.uniform(-3, 10, size=(k, m)).astype(np.float32)
+    out = {}
+    for v in (8, 20, 21):
+        g.set_tuning("f32_variant", v)
+        out[v], _ = g.matmul_capi(a, b)
+    g.set_tuning("f32_variant", -1)
+    assert np.array_equal(out[8], out[20]) and np.array_equal(out[8], out[21])
 
 
 @pytest.mark.parametrize("shape", [(516, 528, 528), (4, 16, 16), (300, 64, 272), (1024, 4112, 512), (260, 8, 4)],

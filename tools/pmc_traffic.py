@@ -23,7 +23,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 WHAT = {"f32": ("mfma_f32_kernel", 4, "float"), "f16": ("mfma_f16_", 2, "half"), "f64": ("mfma_f64_kernel", 8, "double"),
-        "uint8": ("mfma_i8_", 1, "uint8_t"), "minplus": ("valu_tile_kernel", 4, "float (Add,Min)")}
+        "uint8": ("mfma_i8_", 1, "uint8_t"), "minplus": ("valu_tile_", 4, "float (Add,Min)")}
 
 
 def run_pass(counter, size, workdir, what="f32", variant=None):
