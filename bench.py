@@ -156,7 +156,7 @@ def roofline_obj(dtype, roof, peak, rows, k, m, launch_ms):
             "avg_launch_ms": round(1e3 * avg_s, 4)}
 
 
-def extra_workloads(g, torch, dev, local_rank, steps=3):
+def extra_workloads(g, torch, dev, local_rank, steps=5):
     """The other single-GPU BASELINE configs, a few steps each, in the same process."""
     out = []
     jobs = [("half", None), ("double", None), ("minplus", None), ("uint8", None), ("float", C5A_ROWS)]
@@ -166,12 +166,12 @@ def extra_workloads(g, torch, dev, local_rank, steps=3):
         k = m = size
         try:
             a, b, c = alloc_fill(g, torch, dev, local_rank, dtype, rows, k, m, 2000 + len(out), 3000 + len(out))
-            elapsed, launch_ms = timed_steps(g, torch, a, b, c, dtype, map_op, reduce_op, steps, 1, lambda: None)
+            elapsed, launch_ms = timed_steps(g, torch, a, b, c, dtype, map_op, reduce_op, steps, 2, lambda: None)
             value = 1e-9 * 2.0 * rows * k * m * steps / elapsed
             out.append({"workload": f"{dtype} {rows}x{k}x{m} ({map_op},{reduce_op}) on 1 MI355X"
                                     + ("; BASELINE configs[4]'s job without the split" if rows_override else ""),
                         "kernel": g.kernel_name(g.make_config(dtype, map_op, reduce_op), rows, k, m),
-                        "dtype": DTYPE_TAG[dtype], "value": round(value, 1), "unit": "GOp/s", "steps": steps, "warmup": 1,
+                        "dtype": DTYPE_TAG[dtype], "value": round(value, 1), "unit": "GOp/s", "steps": steps, "warmup": 2,
                         "ms_per_step": round(1e3 * elapsed / steps, 4),
                         "roofline": roofline_obj(dtype, roof, peak, rows, k, m, launch_ms)})
         except Exception as exc:  # an extra must never take the headline line down with it
