@@ -534,13 +534,15 @@ int mm_kernel_info(const mm_config_t *cfg, unsigned n, unsigned k, unsigned m, m
       else { r.tile_n = 256; r.tile_m = 256; r.wavefronts = 8; }
       r.tile_k = (r.tile_n == 256 && k % 32 == 0 && k >= 128 && cfg->layout_a == MM_A_ROW_MAJOR) ? 32 : 64;
       r.inst_n = 32; r.inst_m = 32; r.inst_k = 16; r.ops_per_clk_per_cu = 4096.0;
-      // ping-pong schedule: MfmaUtil 84 % at 32768^3 (profiles/r02d_pmc_f16_32768_v11.json); the chip is
-      // power-limited there and delivers ~1.5 GHz, so 0.84 x 2.4 GHz over-predicts wall throughput
-      r.measured_issue_efficiency = r.tile_k == 32 ? 0.84 : 0.67;
+      // ping-pong schedule: MfmaUtil 89.7 % at 32768^3 (profiles/r02i_pmc_f16_32768_v100.json); the chip is
+      // power-limited there and delivers ~1.45 GHz, so 0.90 x 2.4 GHz over-predicts wall throughput
+      r.measured_issue_efficiency = r.tile_k == 32 ? 0.90 : 0.67;
       break;
     case FAM_MFMA_I8:
-      r.tile_n = 256; r.tile_m = 256; r.tile_k = 128; r.wavefronts = 8;
+      r.tile_n = 256; r.tile_m = 256; r.wavefronts = 8;
+      r.tile_k = (k % 64 == 0 && k >= 256 && cfg->layout_a == MM_A_ROW_MAJOR) ? 64 : 128;
       r.inst_n = 32; r.inst_m = 32; r.inst_k = 32; r.ops_per_clk_per_cu = 8192.0;
+      r.measured_issue_efficiency = r.tile_k == 64 ? 0.92 : 0.68;  // profiles/r02i_pmc_i8_32768.json / r01_pmc_i8.json
       break;
     case FAM_VALU_TILE: {
       r.tile_n = 128; r.tile_m = 128; r.tile_k = 16; r.wavefronts = 4;
@@ -551,7 +553,7 @@ int mm_kernel_info(const mm_config_t *cfg, unsigned n, unsigned k, unsigned m, m
       const bool fma = cfg->map_op == MM_OP_MULTIPLY && cfg->reduce_op == MM_OP_ADD && (fp || cfg->dtype == MM_DTYPE_F64);
       const bool m3 = fp && (cfg->reduce_op == MM_OP_MIN || cfg->reduce_op == MM_OP_MAX);
       r.ops_per_clk_per_cu = fma ? 256.0 : (m3 ? 128.0 * 4.0 / 3.0 : 128.0);
-      r.measured_issue_efficiency = 0.65;
+      r.measured_issue_efficiency = 0.65;   // against 2-cycle issue; min/max instructions take 4.2 (profiles/r02_probe_valu_*)
       break;
     }
     default:

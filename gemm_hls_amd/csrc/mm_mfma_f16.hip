@@ -555,24 +555,36 @@ __global__ __launch_bounds__(GeoPP2::THREADS) void mfma_f16_pp2_kernel(const _Fl
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
   const unsigned U = K / G::BK, UD = U / 2;
   // half `h` (pieces wave+16h, wave+16h+8) of A double slab `ds` into A buffer `abuf`, and B slab `slab` into B buffer `bbuf`
+  // cache policy of the DMA loads (experiment knob): VAR bits 2-3 = A pieces, bits 4-5 = B pieces;
+  // 0 default, 1 "nt", 2 "sc1", 3 "sc0 sc1"
+#define MM_PP2_ISSUE(POL, V0, V1, SB, L0, L1)                                                                        \
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3" POL           \
+               "\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3" POL "\n\ts_mov_b32 m0, %0" \
+               : "=&s"(keep)                                                                                         \
+               : "v"(V0), "v"(V1), "s"(SB), "s"(L0), "s"(L1)                                                         \
+               : "memory")
   auto issue_a = [&](unsigned ds, unsigned abuf, int h) {
     const char *ap = a_base + (size_t)min(ds, UD - 1) * 128;
     const unsigned la0 = lds0 + abuf * G::A2_BYTES + (wave + 16 * h) * 1024, la1 = la0 + 8 * 1024;
+    const unsigned v0 = h ? voff_a[2] : voff_a[0], v1 = h ? voff_a[3] : voff_a[1];
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\t" MM_DMA_PIECE("%1", "%3", "%4") MM_DMA_PIECE("%2", "%3", "%5") "s_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(h ? voff_a[2] : voff_a[0]), "v"(h ? voff_a[3] : voff_a[1]), "s"(ap), "s"(la0), "s"(la1)
-                 : "memory");
+    constexpr int POL = (VAR >> 2) & 3;
+    if constexpr (POL == 0) MM_PP2_ISSUE("", v0, v1, ap, la0, la1);
+    else if constexpr (POL == 1) MM_PP2_ISSUE(" nt", v0, v1, ap, la0, la1);
+    else if constexpr (POL == 2) MM_PP2_ISSUE(" sc1", v0, v1, ap, la0, la1);
+    else MM_PP2_ISSUE(" sc0 sc1", v0, v1, ap, la0, la1);
   };
   auto issue_b = [&](unsigned slab, unsigned bbuf) {
     const char *bp = b_base + (size_t)min(slab, U - 1) * G::BK * M * 2;
     const unsigned lb0 = lds0 + G::B_REGION + bbuf * G::B_BYTES + wave * 1024, lb1 = lb0 + 8 * 1024;
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\t" MM_DMA_PIECE("%1", "%3", "%4") MM_DMA_PIECE("%2", "%3", "%5") "s_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(voff_b[0]), "v"(voff_b[1]), "s"(bp), "s"(lb0), "s"(lb1)
-                 : "memory");
+    constexpr int POL = (VAR >> 4) & 3;
+    if constexpr (POL == 0) MM_PP2_ISSUE("", voff_b[0], voff_b[1], bp, lb0, lb1);
+    else if constexpr (POL == 1) MM_PP2_ISSUE(" nt", voff_b[0], voff_b[1], bp, lb0, lb1);
+    else if constexpr (POL == 2) MM_PP2_ISSUE(" sc1", voff_b[0], voff_b[1], bp, lb0, lb1);
+    else MM_PP2_ISSUE(" sc0 sc1", voff_b[0], voff_b[1], bp, lb0, lb1);
   };
+#undef MM_PP2_ISSUE
 
   // ---- fragment addresses.  A: row = wm*128 + mi*32 + lo, logical chunk = 4*h + 2*ks + hi (h = slab parity),
   //      physical = logical ^ ((lo>>1)&7) = (4h | 2ks) ^ c with c = hi ^ ((lo>>1)&7)
@@ -741,8 +753,20 @@ int launch_mfma_f16(hipStream_t s, const Problem &p) {
   if (!mfma_f16_serves(p)) return kErrNotSupported;
   if (p.a_transposed) return launch_h<GeoH, true>(s, p);
   const int v = tuning(TUNE_F16_VARIANT);  // tuning hook
-  if (v == 100 && mfma_f16_pp2_serves(p)) return launch_pp2<0>(s, p);  // full-line A requests
-  if (v == 102 && mfma_f16_pp2_serves(p)) return launch_pp2<2>(s, p);  //   ... in lock step (ablation)
+  if (v >= 100 && v < 200 && mfma_f16_pp2_serves(p)) {  // 100 + VAR of the full-line-A ping-pong kernel
+    switch (v - 100) {
+      case 0: return launch_pp2<0>(s, p);
+      case 2: return launch_pp2<2>(s, p);     // lock step (ablation)
+      case 4: return launch_pp2<4>(s, p);     // A nt
+      case 8: return launch_pp2<8>(s, p);     // A sc1
+      case 16: return launch_pp2<16>(s, p);   // B nt
+      case 32: return launch_pp2<32>(s, p);   // B sc1
+      case 20: return launch_pp2<20>(s, p);   // A nt, B nt
+      case 40: return launch_pp2<40>(s, p);   // A sc1, B sc1
+      case 60: return launch_pp2<60>(s, p);   // A sc0 sc1, B sc0 sc1
+      default: return kErrNotSupported;
+    }
+  }
   if (v >= 10 && v < 100 && mfma_f16_pp_serves(p)) {  // 10 + VAR of the ping-pong kernel
     switch (v - 10) {
       case 0: return launch_pp<0>(s, p);
