@@ -61,8 +61,12 @@ typedef const __attribute__((address_space(1))) void *gptr_t;
 typedef __attribute__((address_space(3))) void *lptr_t;
 
 template <int TM_, int WM_, int WN_, int BK_, int NS_, bool TWO_LEVEL_, int KC_, int FC_ = 0, bool STAGGER_ = false,
-          bool PIN_ = false>
+          bool PIN_ = false, int HINT_ = 0>
 struct Geo {
+  // HINT: sched_group_barrier shaping of a k-group (softer than PIN's sched_barrier fences):
+  //   1: the group's 6 fragment reads first, then its MFMAs; after the slab barrier 4 MFMAs, the 4 DMA
+  //      pieces, the reads, the remaining MFMAs.   2: reads in the middle of the group (8 MFMAs, 6 reads, rest).
+  static constexpr int HINT = HINT_;
   // PIN: a scheduling fence after every group's fragment reads.  Without it hipcc sinks four of the six
   // ds_read_b128 of a k-group down to just before the slab barrier, where the s_waitcnt lgkmcnt(0)
   // that the barrier needs then exposes their full LDS latency once per slab.
@@ -304,12 +308,32 @@ __global__ __launch_bounds__(G::THREADS) void mfma_f32_kernel(const float *__res
         // Slab t+1 must have landed; slabs t+2 .. t+NS-1 may stay in flight across the barrier.
         // This wave's LDS reads of slab t are all in registers (lgkmcnt(0)), so after the
         // barrier its ring slot is free for slab t+NS.
+        if (G::HINT) __builtin_amdgcn_sched_barrier(0);  // the wait + barrier must not float up into the previous group
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NS - 2) * L) : "memory");
         __builtin_amdgcn_s_barrier();
         if (!G::STAGGER || !late) stage(buf, (t + NS) * BK);
         load_frags((t + 1) % NS, 0, afn, bfn);
       }
       mfma_group(afc, bfc);
+      if (G::HINT) {  // masks: MFMA 0x8, VMEM read 0x20, DS read 0x100
+        constexpr int NM = 16 * TM, NR = TM + 4;
+        if (kg + 1 < G::KG) {
+          if (G::HINT == 1) {
+            __builtin_amdgcn_sched_group_barrier(0x100, NR, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
+          } else {
+            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, NR, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, NM - 8, 0);
+          }
+        } else {
+          __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+          __builtin_amdgcn_sched_group_barrier(0x020, L, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, G::HINT == 1 ? 0 : 4, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, NR, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, NM - (G::HINT == 1 ? 4 : 8), 0);
+        }
+      }
     }
   };
 
@@ -611,10 +635,12 @@ using V16 = Geo<2, 4, 2, 16, 2, false, 1, 256, true>;  // V8 + staggered DMA iss
 using V17 = Geo<2, 4, 2, 32, 2, false, 1, 128, true>;  // V10 (256x256x32) + stagger
 using V18 = Geo<2, 4, 2, 16, 2, false, 1, 256, false, true>;  // V8 + pinned fragment reads
 using V19 = Geo<2, 4, 2, 16, 2, false, 1, 256, true, true>;   // V8 + stagger + pinned fragment reads
+using V22 = Geo<2, 4, 2, 16, 2, false, 1, 256, false, false, 1>;  // V8 + sched_group_barrier shaping, reads first
+using V23 = Geo<2, 4, 2, 16, 2, false, 1, 256, false, false, 2>;  // V8 + shaping, reads mid-group
 
 }  // namespace
 
-int mfma_f32_num_variants() { return 22; }
+int mfma_f32_num_variants() { return 24; }
 
 const char *mfma_f32_name(int v) {
   switch (v) {
@@ -640,6 +666,8 @@ const char *mfma_f32_name(int v) {
     case 19: return "mfma_f32_256x256x16_w8_flush4096_stagger_pin";
     case 20: return "mfma_f32_256x256x16_w8_flush4096_pingpong";
     case 21: return "mfma_f32_256x256x16_w8_flush4096_pingpong_lockstep";
+    case 22: return "mfma_f32_256x256x16_w8_flush4096_sgb1";
+    case 23: return "mfma_f32_256x256x16_w8_flush4096_sgb2";
   }
   return "?";
 }
@@ -714,6 +742,8 @@ int launch_mfma_f32(hipStream_t s, const Problem &p, int variant) {
     case 19: return launch_geo<V19>(s, p);
     case 20: return mfma_f32_pp_serves_impl(p) ? launch_f32_pp<0>(s, p) : launch_geo<V8>(s, p);
     case 21: return mfma_f32_pp_serves_impl(p) ? launch_f32_pp<2>(s, p) : launch_geo<V8>(s, p);
+    case 22: return launch_geo<V22>(s, p);
+    case 23: return launch_geo<V23>(s, p);
   }
   return kErrNotSupported;
 }

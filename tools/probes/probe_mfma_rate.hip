@@ -11,7 +11,7 @@
 #include <cstdio>
 #include <vector>
 #include <algorithm>
-#define ITERS 16384
+#define ITERS 65536
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f64x4 = __attribute__((ext_vector_type(4))) double;
@@ -20,26 +20,62 @@ using h8 = __attribute__((ext_vector_type(8))) _Float16;
 using i32x4 = __attribute__((ext_vector_type(4))) int;
 
 // MODE 0: f32 32x32x2   1: f64 16x16x4   2: f16 32x32x16   3: i8 32x32x32
+// MODE 4 / 5: f16 / i8 again, but every MFMA of the unrolled body gets its OWN pseudo-random operand
+// registers (values in [1,10) / full-range bytes), so consecutive MFMAs toggle the multiplier inputs
+// the way a GEMM on the reference's data does: the register-only POWER ceiling of the matrix cores on
+// realistic operands (the constant-operand modes above measure the issue rate at an unrealistically
+// low power).
 template <int MODE, int NACC>
-__global__ __launch_bounds__(1024) void k(float *out, unsigned long long *cyc, float seed) {
-  f32x16 af[NACC]; f64x4 ad[NACC]; i32x16 ai[NACC];
-  for (int i = 0; i < NACC; ++i) { af[i] = (f32x16)(seed * i); ad[i] = (f64x4)((double)seed * i); ai[i] = (i32x16)(i); }
+__global__ __launch_bounds__(512) void k(float *out, unsigned long long *cyc, float seed) {
+  // only the state of THIS mode exists (everything else would spill: 512 threads = 256 registers each)
+  constexpr bool F = MODE == 0 || MODE == 2 || MODE == 4, D = MODE == 1, I = MODE == 3 || MODE == 5;
+  f32x16 af[F ? NACC : 1]; f64x4 ad[D ? NACC : 1]; i32x16 ai[I ? NACC : 1];
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) {
+    if (F) af[i] = (f32x16)(seed * i);
+    if (D) ad[i] = (f64x4)((double)seed * i);
+    if (I) ai[i] = (i32x16)(i);
+  }
   const float xf = seed + threadIdx.x; const double xd = seed + threadIdx.x;
-  h8 xh; for (int j = 0; j < 8; ++j) xh[j] = (_Float16)(seed + j);
+  h8 xh;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) xh[j] = (_Float16)(seed + j);
   i32x4 xi = {(int)threadIdx.x, 1, 2, 3};
+  h8 rh[MODE == 4 ? 2 * NACC : 1];
+  i32x4 ri[MODE == 5 ? 2 * NACC : 1];
+  unsigned st = threadIdx.x * 2654435761u + blockIdx.x * 40503u + 12345u;
+  if (MODE == 4 || MODE == 5) {
+#pragma unroll
+    for (int i = 0; i < 2 * NACC; ++i) {
+      if (MODE == 4) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { st = st * 1664525u + 1013904223u; rh[i][j] = (_Float16)(1.0f + 9.0f * (st >> 8) * (1.0f / 16777216.0f)); }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { st = st * 1664525u + 1013904223u; ri[i][j] = (int)st; }
+      }
+    }
+  }
   __syncthreads();
   const unsigned long long t0 = __builtin_amdgcn_s_memtime();
   for (int it = 0; it < ITERS; ++it) {
 #pragma unroll
     for (int i = 0; i < NACC; ++i) {
-      if (MODE == 0) af[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(xf, xf, af[i], 0, 0, 0);
-      if (MODE == 1) ad[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(xd, xd, ad[i], 0, 0, 0);
-      if (MODE == 2) af[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, xh, af[i], 0, 0, 0);
-      if (MODE == 3) ai[i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(xi, xi, ai[i], 0, 0, 0);
+      if constexpr (MODE == 0) af[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(xf, xf, af[i], 0, 0, 0);
+      if constexpr (MODE == 1) ad[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(xd, xd, ad[i], 0, 0, 0);
+      if constexpr (MODE == 2) af[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, xh, af[i], 0, 0, 0);
+      if constexpr (MODE == 3) ai[i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(xi, xi, ai[i], 0, 0, 0);
+      if constexpr (MODE == 4) af[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(rh[2 * i], rh[2 * i + 1], af[i], 0, 0, 0);
+      if constexpr (MODE == 5) ai[i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ri[2 * i], ri[2 * i + 1], ai[i], 0, 0, 0);
     }
   }
   float s = 0;
-  for (int i = 0; i < NACC; ++i) s += af[i][0] + (float)ad[i][0] + (float)ai[i][0];
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) {
+    if (F) s += af[i][0];
+    if (D) s += (float)ad[i][0];
+    if (I) s += (float)ai[i][0];
+  }
   asm volatile("s_nop 0" ::"v"(s) : "memory");
   const unsigned long long t1 = __builtin_amdgcn_s_memtime();
   out[blockIdx.x * 1024 + threadIdx.x] = s;
@@ -86,6 +122,8 @@ int main() {
     run<0, 4>("v_mfma_f32_32x32x2_f32", 4096, wps, d, dc);
     run<2, 4>("v_mfma_f32_32x32x16_f16", 32768, wps, d, dc);
     run<3, 4>("v_mfma_i32_32x32x32_i8", 65536, wps, d, dc);
+    run<4, 8>("f16 32x32x16, random operands", 32768, wps, d, dc);
+    run<5, 8>("i8 32x32x32, random operands", 65536, wps, d, dc);
   }
   return 0;
 }
