@@ -236,3 +236,12 @@ def test_bench_two_ranks_on_one_device_smoke(scaling):
     rows_total = 6000 if scaling == "strong" else 2 * 2048
     assert out["config"]["rows_total"] == rows_total
     assert abs(out["value"] - 1e-9 * 2.0 * rows_total * 2048 * 2048 * 2 / (out["ms_per_step"] * 2e-3)) / out["value"] < 1e-3
+
+
+def test_race_screen_of_the_hand_synchronised_kernels():
+    """tools/soak.py: every DMA-ring kernel repeated under an uneven background load gives the same bits
+    every time and equals an independently scheduled kernel of the same arithmetic (a few seconds)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "soak.py")], capture_output=True, text=True,
+                       timeout=900, cwd=ROOT)
+    assert r.returncode == 0 and "soak ok" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+    assert " 0 differing results" in r.stdout and "differing results, equal to independent schedule: True" in r.stdout

@@ -1,8 +1,16 @@
 #!/usr/bin/env python3
-"""Race screen: the same launch repeated many times must give the same bits every time (the
-kernels are deterministic by construction: fixed tile ownership, fixed summation order), while other
-work runs concurrently on a second stream to perturb timing.  Also checks against the first result
-of a different geometry where one exists."""
+"""Race screen for the hand-synchronised kernels (counted vmcnt + barriers, LDS rings refilled by
+DMA): the same launch repeated many times must give the same bits every time -- the kernels are
+deterministic by construction (fixed tile ownership, fixed summation order) -- while a second stream
+runs an uneven background load (memory traffic and another GEMM) to perturb DMA landing times.  A
+read that is ordered only by luck shows up here as a rare differing launch (cdna_hip_programming.md:
+"place reads by the vmcnt/barrier count, never by clean runs" -- this is the clean-run screen on top
+of the count).  Every result is also compared bitwise with an INDEPENDENT schedule of the same
+arithmetic where one exists (round-1 one-slab-per-barrier kernels via the tuning knobs).
+
+  python tools/soak.py [--scale 1]
+"""
+import argparse
 import os
 import sys
 import time
@@ -12,27 +20,64 @@ import torch  # noqa: E402
 
 import gemm_hls_amd as g  # noqa: E402
 
+ap = argparse.ArgumentParser()
+ap.add_argument("--scale", type=int, default=1)
+args = ap.parse_args()
+
 dev = torch.device("cuda:0")
 side = torch.cuda.Stream()
 noise = torch.empty(64 << 20, dtype=torch.float32, device=dev)
-for dtype, tdt, n, reps in (("float", torch.float32, 8192, 60), ("half", torch.float16, 8192, 60),
-                            ("double", torch.float64, 4096, 40), ("uint8_t", torch.uint8, 8192, 60)):
-    a = torch.empty((n + 37, n), dtype=tdt, device=dev)   # ragged N on purpose
+na = torch.rand((2048, 2048), device=dev)
+nb = torch.rand((2048, 2048), device=dev)
+
+#      label          dtype      ops                  torch dtype     n     reps  knob          other variant
+CASES = [
+    ("float",        "float",   ("Multiply", "Add"), torch.float32, 8192, 60, "f32_variant", 3),     # 3: no flush -> not bitwise comparable
+    ("half",         "half",    ("Multiply", "Add"), torch.float16, 16384, 150, "f16_variant", 0),
+    ("half K%64=32", "half",    ("Multiply", "Add"), torch.float16, 8224, 100, "f16_variant", 0),    # plain ping-pong (K % 64 != 0)
+    ("double",       "double",  ("Multiply", "Add"), torch.float64, 4096, 40, None, None),
+    ("uint8_t",      "uint8_t", ("Multiply", "Add"), torch.uint8, 16384, 150, "i8_variant", 0),
+    ("uint8 K%128=64", "uint8_t", ("Multiply", "Add"), torch.uint8, 8256, 100, "i8_variant", 0),
+    ("min-plus",     "float",   ("Add", "Min"), torch.float32, 8192, 60, "valu_variant", 0),
+    ("int (x,+)",    "int",     ("Multiply", "Add"), torch.int32, 4096, 40, "valu_variant", 0),
+]
+for label, dtype, ops, tdt, n, reps, knob, other in CASES:
+    reps *= args.scale
+    rows = n + 37                                        # ragged N on purpose
+    a = torch.empty((rows, n), dtype=tdt, device=dev)
     b = torch.empty((n, n), dtype=tdt, device=dev)
     g._check(g.lib().mm_fill_device(0, g.DTYPES[dtype], a.data_ptr(), a.numel(), 5))
     g._check(g.lib().mm_fill_device(0, g.DTYPES[dtype], b.data_ptr(), b.numel(), 6))
-    ref = g.matmul(a, b, dtype).clone()
+    if dtype == "half":                                  # keep the sums finite: an all-inf result compares equal whatever happened
+        a.mul_(2.0 ** -6)
+        b.mul_(2.0 ** -6)
+    name = g.kernel_name(g.make_config(dtype, *ops), rows, n, n)
+    ref = g.matmul(a, b, dtype, *ops).clone()
     torch.cuda.synchronize()
+    if dtype in ("half", "float", "double"):
+        assert bool(torch.isfinite(ref).all()), label
+    same_as_other = None
+    if knob is not None:
+        g.set_tuning(knob, other)
+        alt = g.matmul(a, b, dtype, *ops)
+        g.set_tuning(knob, -1)
+        torch.cuda.synchronize()
+        same_as_other = bool(torch.equal(alt.view(torch.uint8), ref.view(torch.uint8)))
+        if not (label == "float"):
+            assert same_as_other, f"{label}: differs from the independent schedule (variant {other})"
     bad = 0
     t0 = time.perf_counter()
     for i in range(reps):
-        with torch.cuda.stream(side):          # uneven background load on the memory system
-            if i % 3:
+        with torch.cuda.stream(side):                    # uneven background load
+            if i % 3 == 1:
                 noise.mul_(1.0001)
-        c = g.matmul(a, b, dtype)
+            elif i % 3 == 2:
+                g.matmul(na, nb)
+        c = g.matmul(a, b, dtype, *ops)
         if not torch.equal(c.view(torch.uint8), ref.view(torch.uint8)):
             bad += 1
     torch.cuda.synchronize()
-    print(f"{dtype:8s} {n+37}x{n}x{n}: {reps} launches, {bad} differing results, {time.perf_counter()-t0:.1f} s", flush=True)
+    print(f"{label:16s} {name:26s} {rows}x{n}x{n}: {reps} launches, {bad} differing results, "
+          f"equal to independent schedule: {same_as_other}, {time.perf_counter()-t0:.1f} s", flush=True)
     assert bad == 0
 print("soak ok")
