@@ -97,9 +97,9 @@ def hbm_traffic_per_launch():
     """HBM-side bytes per launch of the headline kernel.  NOT measured in this run: rocprofv3's PMC
     passes serialise and slow the kernel, so they are collected separately by tools/pmc_traffic.py
     (separate --pmc FETCH_SIZE / WRITE_SIZE passes, the guide's gfx950 correction) and committed
-    under profiles/; this returns (bytes, source file) of the newest such file, or (None, None)."""
+    under profiles/; this returns (bytes, source file) of the latest round's file, or (None, None)."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")), key=os.path.getmtime)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))  # rNN[x]_ prefixes sort by round
     for path in reversed(files):
         try:
             d = json.load(open(path))
