@@ -180,3 +180,133 @@ def test_xcd_remap_is_a_bijection():
         return base + slot
     for nwg in [1, 7, 8, 9, 63, 64, 65, 1000, 8192, 8191]:
         assert sorted(remap(b, nwg) for b in range(nwg)) == list(range(nwg))
+
+
+# ================================================================ round 2: ping-pong kernels =======
+def b64_half_banks_disjoint(addr_of_lane, lanes):
+    """ds_read_b64 / ds_read_b64_tr_*: served per 32-lane half, bank = (addr/4) % 64; identical addresses
+    broadcast, distinct addresses must not share a bank."""
+    seen = {}
+    for l in lanes:
+        a = addr_of_lane(l)
+        for d in (0, 4):
+            bank = ((a + d) // 4) % 64
+            assert seen.setdefault(bank, a) == a, (l, a, seen[bank])
+
+
+def test_pingpong_a_image_64_byte_rows_roundtrip_and_banks():
+    """mfma_f16_pp_kernel / mfma_i8_pp_kernel / mfma_f32_pp_kernel / valu_tile_dma_kernel: A slab
+    [rows][64 B], DMA piece = 16 rows, source chunk = pc ^ ((row>>2)&3); fragment chunk 2*ks + hi."""
+    lds = {}
+    for piece in range(16):
+        for lane in range(64):
+            row, pc = piece * 16 + lane // 4, lane % 4
+            lds[piece * 1024 + lane * 16] = (row, pc ^ ((row >> 2) & 3))
+    for wm, mi, ks in itertools.product(range(2), range(4), range(2)):
+        def addr(l):
+            lo, hi = l & 31, l >> 5
+            ca = hi ^ ((lo >> 2) & 3)
+            return (wm * 128 + lo) * 64 + ((ca, ca ^ 2)[ks]) * 16 + mi * 32 * 64
+        for l in range(64):
+            row, lc = lds[addr(l)]
+            assert row == wm * 128 + mi * 32 + (l & 31) and lc == 2 * ks + (l >> 5)
+        assert_conflict_free_b128(addr)
+
+
+def test_pingpong_a_image_full_line_rows_roundtrip_and_banks():
+    """mfma_f16_pp2_kernel / mfma_i8_pp2_kernel: A double slab [256 rows][128 B], DMA piece = 8 rows,
+    source chunk = pc ^ ((row>>1)&7); fragment chunk (4*h + 2*ks + hi) for slab parity h."""
+    lds = {}
+    for piece in range(32):
+        for lane in range(64):
+            row, pc = piece * 8 + lane // 8, lane % 8
+            lds[piece * 1024 + lane * 16] = (row, pc ^ ((row >> 1) & 7))
+    for wm, mi, h, ks in itertools.product(range(2), range(4), range(2), range(2)):
+        def addr(l):
+            lo, hi = l & 31, l >> 5
+            ca = hi ^ ((lo >> 1) & 7)
+            return (wm * 128 + lo) * 128 + ((2 * (2 * h + ks)) ^ ca) * 16 + mi * 32 * 128
+        for l in range(64):
+            row, lc = lds[addr(l)]
+            assert row == wm * 128 + mi * 32 + (l & 31) and lc == 4 * h + 2 * ks + (l >> 5)
+        assert_conflict_free_b128(addr)
+
+
+def test_pingpong_f16_b_image_for_64_column_waves():
+    """B slab [32 k][256 cols] halves, DMA piece = 2 k-rows, source chunk = pb ^ ((k&3)<<2); 8 waves
+    as 2 x 4 -> a wave covers 64 columns: logical chunk = wn*8 + ni*4 + 2*gq + ((x&3)>>1)."""
+    BROW = 512
+    lds = {}
+    for piece in range(16):
+        for lane in range(64):
+            kr, pb = piece * 2 + lane // 32, lane % 32
+            lds[piece * 1024 + lane * 16] = (kr, pb ^ ((kr & 3) << 2))
+
+    def element_at(byte_addr):
+        base = (byte_addr // 16) * 16
+        kr, lc = lds[base]
+        return kr, lc * 8 + (byte_addr - base) // 2
+
+    for ks, h, ni, wn in itertools.product(range(2), range(2), range(2), range(4)):
+        def addr(l):
+            x, gq, hi = l & 15, (l >> 4) & 1, l >> 5
+            r = x >> 2
+            logical = wn * 8 + ni * 4 + 2 * gq + ((x & 3) >> 1)
+            return (8 * hi + r) * BROW + (logical ^ (r << 2)) * 16 + (x & 1) * 8 + ks * 16 * BROW + h * 4 * BROW
+        for l in range(64):
+            i, grp = l & 15, l & ~15
+            for j in range(4):   # hardware transpose: out[i][j] = in[4j + (i>>2)][i&3]
+                k, col = element_at(addr(grp + 4 * j + (i >> 2)) + 2 * (i & 3))
+                assert k == ks * 16 + 8 * (l >> 5) + 4 * h + j and col == wn * 64 + ni * 32 + (l & 31)
+        b64_half_banks_disjoint(addr, range(0, 32))
+        b64_half_banks_disjoint(addr, range(32, 64))
+
+
+def test_pingpong_i8_b_image_for_64_column_waves():
+    BROW = 256
+    lds = {}
+    for piece in range(16):
+        for lane in range(64):
+            kr, pb = piece * 4 + lane // 16, lane % 16
+            lds[piece * 1024 + lane * 16] = (kr, pb ^ ((kr & 7) << 1))
+
+    def element_at(byte_addr):
+        base = (byte_addr // 16) * 16
+        kr, lc = lds[base]
+        return kr, lc * 16 + (byte_addr - base)
+
+    for ks, h, ni, wn in itertools.product(range(2), range(2), range(2), range(4)):
+        def addr(l):
+            y, gq, hi = l & 15, (l >> 4) & 1, l >> 5
+            r, q = y >> 1, y & 1
+            return (16 * hi + r) * BROW + 8 * q + ((((wn * 2 + ni) ^ r) * 2) + gq) * 16 + ks * 32 * BROW + h * 8 * BROW
+        for l in range(64):
+            i, grp = l & 15, l & ~15
+            for j in range(8):   # out[i][j] = in[2j + (i>>3)][i&7]
+                k, col = element_at(addr(grp + 2 * j + (i >> 3)) + (i & 7))
+                assert k == ks * 32 + 16 * (l >> 5) + 8 * h + j and col == wn * 64 + ni * 32 + (l & 31)
+        b64_half_banks_disjoint(addr, range(0, 32))
+        b64_half_banks_disjoint(addr, range(32, 64))
+
+
+def test_valu_tile_dma_a_pairs_roundtrip_and_banks():
+    """valu_tile_dma_kernel: A slab [128 rows][16 k] floats; a thread reads the (k, k+1) pair of each of
+    its 8 rows with ds_read_b64; the four ty values of a wave must land on different bank groups."""
+    lds = {}
+    for piece in range(8):
+        for lane in range(64):
+            row, pc = piece * 16 + lane // 4, lane % 4
+            lds[piece * 1024 + lane * 16] = (row, pc ^ ((row >> 2) & 3))
+    for wave, kk, i in itertools.product(range(4), range(0, 16, 2), range(8)):
+        def addr(l):
+            ty = (wave * 64 + l) // 16
+            r = ty * 4 + i if i < 4 else 64 + ty * 4 + (i - 4)
+            return r * 64 + (((kk >> 2) ^ (ty & 3)) * 16) + (kk & 3) * 4
+        for l in range(64):
+            ty = (wave * 64 + l) // 16
+            a = addr(l)
+            row, lc = lds[(a // 16) * 16]
+            assert row == (ty * 4 + i if i < 4 else 64 + ty * 4 + (i - 4))
+            assert lc * 4 + (a % 16) // 4 == kk                        # first element of the pair is k = kk
+        b64_half_banks_disjoint(addr, range(0, 32))
+        b64_half_banks_disjoint(addr, range(32, 64))

@@ -1,0 +1,195 @@
+"""CPU model of the hand-over protocol of the DMA-ring kernels (no GPU needed).
+
+The ping-pong kernels (gemm_hls_amd/csrc/mm_mfma_f16.hip, mm_mfma_i8.hip, the fp32 variant) and the
+DMA-staged VALU kernel (mm_valu_tile.inc) order LDS traffic with nothing but counted `s_waitcnt
+vmcnt(N)` and `s_barrier`.  A wrong count does not fail a test reliably -- the DMA usually lands in
+time anyway -- so the protocol is checked here by construction: each wave's program is replayed as
+a list of (epoch, action), epoch = number of workgroup barriers passed, and two rules are asserted
+for every slab (cdna_hip_programming.md, 8-phase template):
+
+  RAW  a slab is read only in an epoch strictly AFTER the epoch in which EVERY wave executed the
+       wait that retires its own DMA pieces of that slab (the barrier between publishes them);
+  WAR  a buffer is refilled only in an epoch strictly after the last epoch in which any wave read
+       its previous occupant (those reads are complete: lgkmcnt(0) / consumed before the barrier).
+
+vmcnt semantics used: DMA loads retire in issue order; `vmcnt(N)` returns when at most N are
+outstanding, i.e. everything but the N most recently issued pieces has landed."""
+import pytest
+
+
+class Wave:
+    def __init__(self):
+        self.epoch = 0
+        self.issued = []     # (what, pieces) in issue order
+        self.reads = []      # (epoch, what)
+        self.issues = []     # (epoch, what)
+        self.retired = {}    # what -> epoch of the wait that covers it
+
+    def barrier(self):
+        self.epoch += 1
+
+    def issue(self, what, pieces):
+        self.issued.append((what, pieces))
+        self.issues.append((self.epoch, what))
+
+    def wait_vmcnt(self, n):
+        outstanding = 0
+        keep = 0
+        for what, pieces in reversed(self.issued):   # the newest pieces may stay in flight
+            if outstanding + pieces <= n:
+                outstanding += pieces
+                keep += 1
+            else:
+                break
+        for what, _ in self.issued[:len(self.issued) - keep]:
+            self.retired.setdefault(what, self.epoch)
+
+    def read(self, what):
+        self.reads.append((self.epoch, what))
+
+
+def check(waves, buffer_of, what_label="slab"):
+    every = set()
+    for w in waves:
+        every |= {what for _, what in w.reads}
+    for what in every:
+        published = 1 + max(w.retired.get(what, 10 ** 9) for w in waves)
+        first_read = min(e for w in waves for e, x in w.reads if x == what)
+        assert first_read >= published, f"RAW: {what_label} {what} read in epoch {first_read}, published in {published}"
+    # WAR: an issue of X into buffer b must come after every read of the previous occupant of b
+    for w in waves:
+        for e_issue, what in w.issues:
+            b = buffer_of(what)
+            prev = [x for x in every if buffer_of(x) == b and x < what]
+            if not prev:
+                continue
+            occupant = max(prev)
+            last_read = max(e for v in waves for e, x in v.reads if x == occupant)
+            assert e_issue > last_read, f"WAR: {what} issued into buffer {b} in epoch {e_issue}, {occupant} still read in {last_read}"
+
+
+@pytest.mark.parametrize("slabs", [4, 5, 7, 16, 33])
+@pytest.mark.parametrize("lockstep", [False, True])
+def test_pingpong_ring_of_four(slabs, lockstep):
+    """mfma_f16_pp_kernel / mfma_i8_pp_kernel / mfma_f32_pp_kernel: 4-slab ring, 4 pieces per wave per
+    slab, vmcnt(8) at the end of every load segment, groups one barrier apart."""
+    waves = []
+    for group in (0, 1):
+        w = Wave()
+        for s in range(3):
+            w.issue(s, 4)
+        w.wait_vmcnt(8)
+        w.barrier()
+        if group == 1 and not lockstep:
+            w.barrier()
+        for u in range(slabs):
+            w.read(u)
+            w.issue(u + 3, 4)            # past the end: harmless re-fetch into a dead buffer
+            w.wait_vmcnt(8)
+            w.barrier()                  # load segment ends; compute segment
+            w.barrier()
+        waves.append(w)
+    check(waves, lambda slab: slab % 4)
+    # both groups execute the same number of barriers once group 0 adds its final extra one
+    assert waves[1].epoch - waves[0].epoch == (0 if lockstep else 1)
+
+
+@pytest.mark.parametrize("slabs", [8, 10, 18, 32])
+def test_pingpong_full_line_a_requests(slabs):
+    """mfma_f16_pp2_kernel / mfma_i8_pp2_kernel: A in double slabs (ring of 3, two halves of 2 pieces
+    per wave), B in slabs (ring of 4, 2 pieces per wave); prologue in the order of four virtual
+    segments; vmcnt(8) at the end of every load segment."""
+    A = lambda d: ("A", d)
+    B = lambda s: ("B", s)
+    waves = []
+    for group in (0, 1):
+        w = Wave()
+        w.issue(("Ah", 0, 0), 2)
+        w.issue(("Ah", 0, 1), 2)
+        w.issue(B(0), 2)
+        w.issue(("Ah", 1, 0), 2)
+        w.issue(B(1), 2)
+        w.issue(("Ah", 1, 1), 2)
+        w.issue(B(2), 2)
+        w.wait_vmcnt(8)
+        w.barrier()
+        if group == 1:
+            w.barrier()
+        for u in range(slabs):
+            w.read(A(u // 2))
+            w.read(B(u))
+            w.issue(("Ah", u // 2 + 2, u % 2), 2)
+            w.issue(B(u + 3), 2)
+            w.wait_vmcnt(8)
+            w.barrier()
+            w.barrier()
+        waves.append(w)
+    # fold the two halves of an A double slab into one object: retired when both halves are, issued at the first
+    for w in waves:
+        for d in range(slabs // 2 + 2):
+            halves = [w.retired.get(("Ah", d, h)) for h in (0, 1)]
+            if all(h is not None for h in halves):
+                w.retired[A(d)] = max(halves)
+        w.issues = [(e, A(x[1]) if x[0] == "Ah" else x) for e, x in w.issues]
+
+    def buffer_of(x):
+        return ("A", x[1] % 3) if x[0] == "A" else ("B", x[1] % 4)
+    check(waves, buffer_of)
+
+
+@pytest.mark.parametrize("slabs", [1, 2, 3, 9])
+def test_valu_tile_dma_double_buffer(slabs):
+    """valu_tile_dma_kernel: ring of 2, per slab: vmcnt(0), barrier, issue the next slab, compute this one."""
+    waves = []
+    for _ in range(4):
+        w = Wave()
+        w.issue(0, 4)
+        for t in range(slabs):
+            w.wait_vmcnt(0)
+            w.barrier()
+            if t + 1 < slabs:
+                w.issue(t + 1, 4)
+            w.read(t)
+        waves.append(w)
+    check(waves, lambda slab: slab % 2)
+
+
+def test_the_model_catches_a_wrong_count():
+    """The same ring-of-four program with vmcnt(12) (one slab too lenient) must violate RAW, and a
+    refill issued one segment early must violate WAR -- otherwise the checks above prove nothing."""
+    waves = []
+    for group in (0, 1):
+        w = Wave()
+        for s in range(3):
+            w.issue(s, 4)
+        w.wait_vmcnt(8)
+        w.barrier()
+        if group == 1:
+            w.barrier()
+        for u in range(8):
+            w.read(u)
+            w.issue(u + 3, 4)
+            w.wait_vmcnt(12)
+            w.barrier()
+            w.barrier()
+        waves.append(w)
+    with pytest.raises(AssertionError, match="RAW"):
+        check(waves, lambda slab: slab % 4)
+    waves = []
+    for group in (0, 1):
+        w = Wave()
+        for s in range(3):
+            w.issue(s, 4)
+        w.wait_vmcnt(8)
+        w.barrier()
+        if group == 1:
+            w.barrier()
+        for u in range(8):
+            w.read(u)
+            w.issue(u + 4, 4)            # into the buffer the OTHER group is still reading
+            w.wait_vmcnt(8)
+            w.barrier()
+            w.barrier()
+        waves.append(w)
+    with pytest.raises(AssertionError):
+        check(waves, lambda slab: slab % 4)
