@@ -50,6 +50,15 @@ WORKLOADS = {
     "uint8": ("uint8_t", "Multiply", "Add", 32768, "mfma", 5000.0),
 }
 DTYPE_TAG = {"float": "f32", "half": "f16 (f32 accumulate)", "double": "f64", "uint8_t": "u8 (i32 accumulate)"}
+# Context for the two power-limited workloads (not a roof this file prices against: `peak` stays the
+# guide's dense MFMA peak): what the matrix cores sustain from registers alone, no LDS and no memory, on
+# different random operands per MFMA at this board's power limit (tools/probes/probe_mfma_rate.hip).
+POWER_CEILING = {
+    "half": {"register_only_mfma_on_random_operands_TOps": 1778.0, "clock_GHz": 1.70,
+             "source": "profiles/r02s_probe_mfma_issue_rates_and_power_ceiling.txt"},
+    "uint8_t": {"register_only_mfma_on_random_operands_TOps": 3532.0, "clock_GHz": 1.68,
+                "source": "profiles/r02s_probe_mfma_issue_rates_and_power_ceiling.txt"},
+}
 
 
 def cpu_baseline(sample_n=1024):
@@ -153,7 +162,8 @@ def roofline_obj(dtype, roof, peak, rows, k, m, launch_ms):
             "frac": round(achieved / peak, 4), "traffic": None,
             "algorithmic_flops_per_launch": 2.0 * rows * k * m,
             "algorithmic_bytes_per_launch": float((rows * k + k * m + rows * m) * es),
-            "avg_launch_ms": round(1e3 * avg_s, 4)}
+            "avg_launch_ms": round(1e3 * avg_s, 4),
+            **({"power_ceiling": POWER_CEILING[dtype]} if dtype in POWER_CEILING else {})}
 
 
 def extra_workloads(g, torch, dev, local_rank, steps=5):
