@@ -231,3 +231,31 @@ def test_max_reduce_over_all_negative_values_uses_lowest_identity(dtype, path):
     assert np.all(c.astype(np.float64) < 0)
     # independent of the oracle: numpy in the native type (rounding is monotone, so max commutes with it)
     assert np.array_equal(c, (a[:, :, None] + b[None]).max(axis=1))
+
+
+# ---- extra bench workload: uint8 (Multiply, Add) 32768^3 on the int8 matrix core ---------------------------
+def test_uint8_32768_bit_exact_against_ordered_kernel_and_naive():
+    """bench.py's workloads[] times uint8 32768^3; parity at that size: the whole output of the ping-pong
+    MFMA kernel equals the k-ordered kernel's (wrap-around 8-bit arithmetic is order-independent), sampled
+    rows x column blocks equal the CPU Naive, on full-range bytes (sign bit included)."""
+    import torch
+    n = k = m = 32768
+    dev = torch.device("cuda:0")
+    g0 = torch.Generator(device=dev)
+    g0.manual_seed(91)
+    a = torch.randint(0, 256, (n, k), dtype=torch.int16, device=dev, generator=g0).to(torch.uint8)
+    b = torch.randint(0, 256, (k, m), dtype=torch.int16, device=dev, generator=g0).to(torch.uint8)
+    assert g.kernel_name(g.make_config("uint8_t"), n, k, m) == "mfma_i8"
+    c = g.matmul(a, b, "uint8_t")
+    torch.cuda.synchronize()
+    rows, cols = _sample(n, m)
+    ah, bh, ch = _host_slices(a, b, c, rows, cols)
+    assert np.array_equal(ch, _oracle.naive("uint8_t", "Multiply", "Add", ah, bh))
+    # the k-ordered kernel on row slabs (it is ~100x slower than the matrix core: 2048 rows are enough)
+    for r0 in (0, n // 2 - 1024, n - 2048):
+        c_ord = g.matmul(a[r0:r0 + 2048].contiguous(), b, "uint8_t", path=g.PATH_ORDERED)
+        assert torch.equal(c_ord, c[r0:r0 + 2048]), r0
+    assert torch.equal(g.matmul(a, b, "uint8_t"), c)
+    # the same bytes read as int8_t give the same result bytes (u8 = s8 mod 2^8)
+    c_s = g.matmul(a.view(torch.int8), b.view(torch.int8), "int8_t")
+    assert torch.equal(c_s.view(torch.uint8), c)
