@@ -53,6 +53,15 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise MMError(f"{LIB_PATH} is missing: run `python gemm_hls_amd/build.py` "
                           "(or __graft_entry__.build()); there is no fallback implementation")
+        # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64 (same SONAME as
+        # /opt/rocm's).  Whichever is loaded first serves both, but if THIS library came first and
+        # torch then brought a second runtime, the second HSA initialisation finds no device
+        # ("no ROCm-capable device is detected").  So torch -- the plumbing for device memory and
+        # streams in this binding anyway -- is imported first whenever it is installed.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = ctypes.CDLL(LIB_PATH)
         vp, u, i, sz = ctypes.c_void_p, ctypes.c_uint, ctypes.c_int, ctypes.c_size_t
         cfgp = ctypes.POINTER(Config)

@@ -250,3 +250,18 @@ def test_race_screen_of_the_hand_synchronised_kernels():
                        timeout=900, cwd=ROOT)
     assert r.returncode == 0 and "soak ok" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
     assert " 0 differing results" in r.stdout and "differing results, equal to independent schedule: True" in r.stdout
+
+
+def test_library_loaded_before_torch_still_sees_the_gpu():
+    """PyTorch-ROCm bundles its own HIP runtime; two runtimes in one process leave the second one
+    without a device.  The binding imports torch first for that reason, so loading it (or running
+    __graft_entry__.build()) BEFORE the first torch import must work -- the order the driver may use."""
+    code = ("import __graft_entry__ as e, sys\n"
+            "import gemm_hls_amd as g\n"
+            "L = g.lib(); assert g.device_count() >= 1\n"
+            "import torch\n"
+            "a = torch.full((64, 64), 2.0, device='cuda')\n"
+            "assert float(g.matmul(a, a)[3, 5]) == 256.0\n"
+            "e.smoke()\n")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0 and "smoke ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
