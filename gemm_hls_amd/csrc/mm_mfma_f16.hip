@@ -321,7 +321,7 @@ struct GeoPP {
 // bit 4: no DMA in the main loop; bit 5: no fragment reads in the main loop (the first slab's are reused);
 // bit 6: every workgroup streams tile (0, 0)'s panels (all DMA traffic becomes L2 hits: splits the
 //        CU-side cost of the DMA path from the fabric / HBM side).
-template <int VAR>
+template <int VAR, bool AT = false>  // AT: A stored K x N (MM_TRANSPOSED_A): the A slab is staged and gathered exactly like B's
 __global__ __launch_bounds__(GeoPP::THREADS) void mfma_f16_pp_kernel(const _Float16 *__restrict__ A,
                                                                        const _Float16 *__restrict__ B,
                                                                        _Float16 *__restrict__ C, unsigned N, unsigned K,
@@ -350,18 +350,19 @@ __global__ __launch_bounds__(GeoPP::THREADS) void mfma_f16_pp_kernel(const _Floa
     const unsigned piece = wave + 8 * i;               // 16 A pieces of 16 rows x 64 B
     const unsigned row = piece * 16 + lane / 4, pc = lane % 4;
     const unsigned chunk = pc ^ ((row >> 2) & 3u);
-    voff_a[i] = (min(row0 + row, N - 1) - row0) * K * 2 + chunk * 16;
     const unsigned kr = piece * 2 + lane / 32, pb = lane % 32;  // 16 B pieces of 2 k-rows x 512 B
     const unsigned lc = pb ^ ((kr & 3u) << 2);
+    voff_a[i] = AT ? kr * N * 2 + (min(row0 + lc * 8, N - 8) - row0) * 2  // K x N: 2 k-rows x 256 tile rows, like B
+                   : (min(row0 + row, N - 1) - row0) * K * 2 + chunk * 16;
     voff_b[i] = kr * M * 2 + (min(col0 + lc * 8, M - 8) - col0) * 2;
   }
-  const char *a_base = (const char *)A + ((VAR & 64) ? 0 : (size_t)row0 * K * 2);
+  const char *a_base = (const char *)A + ((VAR & 64) ? 0 : AT ? (size_t)row0 * 2 : (size_t)row0 * K * 2);
   const char *b_base = (const char *)B + ((VAR & 64) ? 0 : (size_t)col0 * 2);
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
   const unsigned U = K / G::BK;
   auto issue = [&](unsigned slab, unsigned buf) {
     const unsigned sl = min(slab, U - 1);               // past the end: harmless re-fetch into a dead buffer
-    const char *ap = a_base + (size_t)sl * (G::BK * 2);
+    const char *ap = a_base + (AT ? (size_t)sl * G::BK * N * 2 : (size_t)sl * (G::BK * 2));
     const char *bp = b_base + (size_t)sl * G::BK * M * 2;
     const unsigned la0 = lds0 + buf * G::STAGE_BYTES + wave * 1024, la1 = la0 + 8 * 1024;
     const unsigned lb0 = la0 + G::A_BYTES, lb1 = lb0 + 8 * 1024;
@@ -387,6 +388,12 @@ __global__ __launch_bounds__(GeoPP::THREADS) void mfma_f16_pp_kernel(const _Floa
   for (int ni = 0; ni < TN; ++ni) {
     const unsigned logical = wn * 8 + ni * 4 + 2 * gq + ((x & 3u) >> 1);
     b_off[ni] = G::A_BYTES + (8 * hi + r) * G::BROW + (logical ^ (r << 2)) * 16 + (x & 1u) * 8;
+  }
+  unsigned at_off[TM];  // K x N layout of A: the same gather over the [k][256 rows] image (this wave's rows wm*128 ..)
+#pragma unroll
+  for (int mi = 0; mi < TM; ++mi) {
+    const unsigned logical = wm * 16 + mi * 4 + 2 * gq + ((x & 3u) >> 1);
+    at_off[mi] = (8 * hi + r) * (G::BM * 2) + (logical ^ (r << 2)) * 16 + (x & 1u) * 8;
   }
 
   f32x16 acc[TM][TN];
@@ -418,7 +425,16 @@ __global__ __launch_bounds__(GeoPP::THREADS) void mfma_f16_pp_kernel(const _Floa
         bf[ni][ks] = join(v0, v1);
       }
 #pragma unroll
-      for (int mi = 0; mi < TM; ++mi) af[mi][ks] = *(const h8 *)(base + a_off[ks] + mi * 32 * (G::BK * 2));
+      for (int mi = 0; mi < TM; ++mi) {
+        if (AT) {
+          const char *p = base + at_off[mi] + ks * 16 * (G::BM * 2);
+          const s4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s4 __attribute__((address_space(3))) *)(lptr_t)p);
+          const s4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s4 __attribute__((address_space(3))) *)(lptr_t)(p + 4 * G::BM * 2));
+          af[mi][ks] = join(v0, v1);
+        } else {
+          af[mi][ks] = *(const h8 *)(base + a_off[ks] + mi * 32 * (G::BK * 2));
+        }
+      }
     }
     if (VAR & 32) {
 #pragma unroll
@@ -719,14 +735,17 @@ static int launch_h(hipStream_t s, const Problem &p) {
 bool mfma_f16_pp_serves(const Problem &p) {
   return !p.a_transposed && p.k % 32 == 0 && p.k >= 128 && p.m % 8 == 0 && p.m >= 8 && p.n >= 1;
 }
+bool mfma_f16_pp_at_serves(const Problem &p) {
+  return p.a_transposed && p.k % 32 == 0 && p.k >= 128 && p.m % 8 == 0 && p.m >= 8 && p.n % 8 == 0 && p.n >= 8;
+}
 
-template <int VAR>
+template <int VAR, bool AT = false>
 static int launch_pp(hipStream_t s, const Problem &p) {
   using G = GeoPP;
   const unsigned tiles_n = (p.n + G::BM - 1) / G::BM, tiles_m = (p.m + G::BN - 1) / G::BN;
   static unsigned long long configured = 0;
-  if (int e = ensure_dynamic_lds((const void *)mfma_f16_pp_kernel<VAR>, G::LDS_BYTES, configured)) return e;
-  hipLaunchKernelGGL((mfma_f16_pp_kernel<VAR>), dim3(tiles_n * tiles_m), dim3(G::THREADS), G::LDS_BYTES, s,
+  if (int e = ensure_dynamic_lds((const void *)mfma_f16_pp_kernel<VAR, AT>, G::LDS_BYTES, configured)) return e;
+  hipLaunchKernelGGL((mfma_f16_pp_kernel<VAR, AT>), dim3(tiles_n * tiles_m), dim3(G::THREADS), G::LDS_BYTES, s,
                      (const _Float16 *)p.a, (const _Float16 *)p.b, (_Float16 *)p.c, p.n, p.k, p.m, tiles_n, tiles_m, band_rows());
   return (int)hipGetLastError();
 }
@@ -751,8 +770,11 @@ int mfma_f16_tile(const Problem &p) {  // 0: 256x256, 4: 128x256
 
 int launch_mfma_f16(hipStream_t s, const Problem &p) {
   if (!mfma_f16_serves(p)) return kErrNotSupported;
-  if (p.a_transposed) return launch_h<GeoH, true>(s, p);
   const int v = tuning(TUNE_F16_VARIANT);  // tuning hook
+  if (p.a_transposed) {  // K x N A: ping-pong when the shape allows it (variant 0 pins the round-1 kernel)
+    if (v != 0 && mfma_f16_pp_at_serves(p)) return launch_pp<1, true>(s, p);
+    return launch_h<GeoH, true>(s, p);
+  }
   if (v >= 100 && v < 200 && mfma_f16_pp2_serves(p)) {  // 100 + VAR of the full-line-A ping-pong kernel
     switch (v - 100) {
       case 0: return launch_pp2<0>(s, p);

@@ -261,7 +261,7 @@ struct GeoI8PP {
 };
 #define MM_DMA_PIECE(vo, sb, la) "s_mov_b32 m0, " la "\n\ts_nop 0\n\tglobal_load_lds_dwordx4 " vo ", " sb "\n\t"
 
-template <int VAR>  // bit 1: lock-step ablation (no antiphase)
+template <int VAR, bool AT = false>  // VAR bit 1: lock-step ablation; AT: A stored K x N, staged and gathered like B
 __global__ __launch_bounds__(GeoI8PP::THREADS) void mfma_i8_pp_kernel(const signed char *__restrict__ A,
                                                                         const signed char *__restrict__ B,
                                                                         signed char *__restrict__ C, unsigned N, unsigned K,
@@ -286,18 +286,19 @@ __global__ __launch_bounds__(GeoI8PP::THREADS) void mfma_i8_pp_kernel(const sign
   for (int i = 0; i < 2; ++i) {
     const unsigned piece = wave + 8 * i;
     const unsigned row = piece * 16 + lane / 4, pc = lane % 4;         // 16 A pieces of 16 rows x 64 B
-    voff_a[i] = (min(row0 + row, N - 1) - row0) * K + (pc ^ ((row >> 2) & 3u)) * 16;
     const unsigned kr = piece * 4 + lane / 16, pb = lane % 16;         // 16 B pieces of 4 k-rows x 256 B
     const unsigned lc = pb ^ ((kr & 7u) << 1);
+    voff_a[i] = AT ? kr * N + (min(row0 + lc * 16, N - 16) - row0)
+                   : (min(row0 + row, N - 1) - row0) * K + (pc ^ ((row >> 2) & 3u)) * 16;
     voff_b[i] = kr * M + (min(col0 + lc * 16, M - 16) - col0);
   }
-  const char *a_base = (const char *)A + (size_t)row0 * K;
+  const char *a_base = (const char *)A + (AT ? (size_t)row0 : (size_t)row0 * K);
   const char *b_base = (const char *)B + col0;
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
   const unsigned U = K / G::BK;
   auto issue = [&](unsigned slab, unsigned buf) {
     const unsigned sl = min(slab, U - 1);
-    const char *ap = a_base + (size_t)sl * G::BK;
+    const char *ap = a_base + (AT ? (size_t)sl * G::BK * N : (size_t)sl * G::BK);
     const char *bp = b_base + (size_t)sl * G::BK * M;
     const unsigned la0 = lds0 + buf * G::STAGE_BYTES + wave * 1024, la1 = la0 + 8 * 1024;
     const unsigned lb0 = la0 + G::A_BYTES, lb1 = lb0 + 8 * 1024;
@@ -321,6 +322,10 @@ __global__ __launch_bounds__(GeoI8PP::THREADS) void mfma_i8_pp_kernel(const sign
 #pragma unroll
   for (int ni = 0; ni < TN; ++ni)
     b_off[ni] = G::A_BYTES + (16 * hi + r) * G::BROW + 8 * q + ((((wn * 2 + ni) ^ r) * 2) + gq) * 16;
+  unsigned at_off[TM];  // K x N A: the same gather over the [k][256 rows] image
+#pragma unroll
+  for (int mi = 0; mi < TM; ++mi)
+    at_off[mi] = (16 * hi + r) * G::BM + 8 * q + ((((wm * 4 + mi) ^ r) * 2) + gq) * 16;
 
   i32x16 acc[TM][TN];
 #pragma unroll
@@ -347,7 +352,16 @@ __global__ __launch_bounds__(GeoI8PP::THREADS) void mfma_i8_pp_kernel(const sign
         bf[ni][ks] = join(v0, v1);
       }
 #pragma unroll
-      for (int mi = 0; mi < TM; ++mi) af[mi][ks] = *(const i32x4 *)(base + a_off[ks] + mi * 32 * G::BK);
+      for (int mi = 0; mi < TM; ++mi) {
+        if (AT) {
+          const char *p = base + at_off[mi] + ks * 32 * G::BM;
+          const v2i v0 = __builtin_amdgcn_ds_read_tr8_b64_v2i32((v2i __attribute__((address_space(3))) *)(lptr_t)p);
+          const v2i v1 = __builtin_amdgcn_ds_read_tr8_b64_v2i32((v2i __attribute__((address_space(3))) *)(lptr_t)(p + 8 * G::BM));
+          af[mi][ks] = join(v0, v1);
+        } else {
+          af[mi][ks] = *(const i32x4 *)(base + a_off[ks] + mi * 32 * G::BK);
+        }
+      }
     }
     issue(u + 3, (BUF + 3) & 3);
     asm volatile("s_waitcnt vmcnt(8)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
@@ -586,13 +600,17 @@ bool mfma_i8_pp_serves(const Problem &p) {
   return !p.a_transposed && p.k % 64 == 0 && p.k >= 256 && p.m % 16 == 0 && p.m >= 16 && p.n >= 1;
 }
 
-template <int VAR>
+bool mfma_i8_pp_at_serves(const Problem &p) {
+  return p.a_transposed && p.k % 64 == 0 && p.k >= 256 && p.m % 16 == 0 && p.m >= 16 && p.n % 16 == 0 && p.n >= 16;
+}
+
+template <int VAR, bool AT = false>
 static int launch_i8_pp(hipStream_t s, const Problem &p) {
   using G = GeoI8PP;
   const unsigned tiles_n = (p.n + G::BM - 1) / G::BM, tiles_m = (p.m + G::BN - 1) / G::BN;
   static unsigned long long configured = 0;
-  if (int e = ensure_dynamic_lds((const void *)mfma_i8_pp_kernel<VAR>, G::LDS_BYTES, configured)) return e;
-  hipLaunchKernelGGL((mfma_i8_pp_kernel<VAR>), dim3(tiles_n * tiles_m), dim3(G::THREADS), G::LDS_BYTES, s,
+  if (int e = ensure_dynamic_lds((const void *)mfma_i8_pp_kernel<VAR, AT>, G::LDS_BYTES, configured)) return e;
+  hipLaunchKernelGGL((mfma_i8_pp_kernel<VAR, AT>), dim3(tiles_n * tiles_m), dim3(G::THREADS), G::LDS_BYTES, s,
                      (const signed char *)p.a, (const signed char *)p.b, (signed char *)p.c, p.n, p.k, p.m, tiles_n, tiles_m,
                      band_rows());
   return (int)hipGetLastError();
@@ -616,6 +634,7 @@ int launch_mfma_i8(hipStream_t s, const Problem &p) {
   // i8_variant knob: 0 = one-slab-per-barrier kernel, 10 = ping-pong, 12 = ping-pong in lock step
   // (ablation), 100 = ping-pong with full-line A requests; default: the best the shape allows
   const int v = tuning(TUNE_I8_VARIANT);
+  if (mfma_i8_pp_at_serves(p) && v != 0) return launch_i8_pp<0, true>(s, p);  // K x N A on the ping-pong schedule
   if (mfma_i8_pp2_serves(p) && (v < 0 || v == 100)) return launch_i8_pp2(s, p);
   if (mfma_i8_pp_serves(p) && v != 0) return v == 12 ? launch_i8_pp<2>(s, p) : launch_i8_pp<0>(s, p);
   using G = GeoI8;

@@ -219,6 +219,34 @@ def test_i8_mfma_every_schedule_is_bit_exact(dtype, variant, shape):
     assert np.array_equal(c, _oracle.naive(dtype, "Multiply", "Add", a, b))
 
 
+@pytest.mark.parametrize("dtype,shape", [("half", (520, 576, 528)), ("half", (264, 4096, 272)), ("half", (1024, 160, 1032)),
+                                         ("uint8_t", (528, 576, 528)), ("int8_t", (272, 4160, 272)), ("uint8_t", (1024, 256, 1040))],
+                         ids=lambda v: str(v))
+def test_f16_i8_transposed_a_on_the_pingpong_schedule(dtype, shape):
+    """MM_TRANSPOSED_A on shapes the ping-pong kernels take (K % 32 / % 64): the K x N A is staged and
+    gathered like B; results are bit-identical to the row-major ping-pong path AND to the round-1
+    K x N kernel (variant 0)."""
+    n, k, m = shape
+    rng = np.random.default_rng(k + n)
+    if dtype == "half":
+        a = rng.uniform(-2, 2, size=(n, k)).astype(np.float16)
+        b = rng.uniform(-2, 2, size=(k, m)).astype(np.float16)
+    else:
+        a = rng.integers(0, 256, size=(n, k), dtype=np.uint8).view(_oracle.NP_DTYPES[dtype])
+        b = rng.integers(0, 256, size=(k, m), dtype=np.uint8).view(_oracle.NP_DTYPES[dtype])
+    at = np.ascontiguousarray(a.T)
+    knob = "f16_variant" if dtype == "half" else "i8_variant"
+    c_rm, _ = g.matmul_capi(a, b, dtype)
+    c_at, _ = g.matmul_capi(at, b, dtype, transposed_a=True)
+    g.set_tuning(knob, 0)
+    c_old, _ = g.matmul_capi(at, b, dtype, transposed_a=True)
+    g.set_tuning(knob, -1)
+    assert np.array_equal(c_at.view(np.uint8), c_rm.view(np.uint8))
+    assert np.array_equal(c_at.view(np.uint8), c_old.view(np.uint8))
+    if dtype != "half":
+        assert np.array_equal(c_at, _oracle.naive(dtype, "Multiply", "Add", a, b))
+
+
 def test_f16_overflow_behaviour_matches_ieee():
     # K large enough that sums pass 65504: binary16 result is +inf, like a correctly rounded result
     n, k, m = 33, 4096, 64
