@@ -87,9 +87,9 @@ mm_config_t default_cfg() {
 std::once_flag g_tuning_once;
 std::atomic<int> g_tuning[mm::TUNE_COUNT];
 const char *const kTuneName[mm::TUNE_COUNT] = {"f32_variant", "f64_variant", "f16_variant", "i8_variant", "band_rows",
-                                               "valu_variant"};
+                                               "valu_variant", "ablations"};
 const char *const kTuneEnv[mm::TUNE_COUNT] = {"MM_F32_VARIANT", "MM_F64_VARIANT", "MM_F16_VARIANT", "MM_I8_VARIANT",
-                                              "MM_BAND_ROWS", "MM_VALU_VARIANT"};
+                                              "MM_BAND_ROWS", "MM_VALU_VARIANT", "MM_ABLATIONS"};
 void tuning_init() {
   for (int i = 0; i < mm::TUNE_COUNT; ++i) {
     const char *e = getenv(kTuneEnv[i]);

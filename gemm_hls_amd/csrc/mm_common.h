@@ -123,6 +123,8 @@ enum Tunable {
   TUNE_I8_VARIANT,       // MM_I8_VARIANT
   TUNE_BAND_ROWS,        // MM_BAND_ROWS    tile-rows per rasterisation band
   TUNE_VALU_VARIANT,     // MM_VALU_VARIANT 0 = synchronous valu_tile kernel, else (default) the DMA-staged one
+  TUNE_ABLATIONS,        // MM_ABLATIONS    1 = allow the variants that skip work on purpose (power breakdown
+                         //                 measurements; they produce WRONG results and are refused otherwise)
   TUNE_COUNT
 };
 int tuning(Tunable t);  // mm_capi.hip

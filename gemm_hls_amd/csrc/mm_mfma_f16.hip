@@ -790,6 +790,8 @@ int launch_mfma_f16(hipStream_t s, const Problem &p) {
     }
   }
   if (v >= 10 && v < 100 && mfma_f16_pp_serves(p)) {  // 10 + VAR of the ping-pong kernel
+    // VAR bits 4-6 skip work on purpose (wrong results): only for the power-breakdown measurements
+    if (((v - 10) & 0x70) && tuning(TUNE_ABLATIONS) != 1) return kErrNotSupported;
     switch (v - 10) {
       case 0: return launch_pp<0>(s, p);
       case 1: return launch_pp<1>(s, p);

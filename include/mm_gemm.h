@@ -179,7 +179,8 @@ typedef struct {
 int mm_kernel_info(const mm_config_t *cfg, unsigned size_n, unsigned size_k, unsigned size_m,
                    mm_kernel_info_t *info);
 /* Tuning knobs for sweeps and ablations ("f32_variant", "f64_variant", "f16_variant",
- * "i8_variant", "valu_variant", "band_rows"; -1 = the library's own choice).  Each is initialised ONCE from its
+ * "i8_variant", "valu_variant", "band_rows"; -1 = the library's own choice; "ablations" = 1 unlocks the
+ * measurement-only variants that skip work and therefore return wrong results).  Each is initialised ONCE from its
  * environment variable (MM_F32_VARIANT, ...) and changed only through this call afterwards; the
  * launch path never reads the environment.  No reference counterpart (the reference's tile sizes
  * are CMake cache variables, CMakeLists.txt:18-20). */

@@ -265,3 +265,23 @@ def test_library_loaded_before_torch_still_sees_the_gpu():
             "e.smoke()\n")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0 and "smoke ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_ablation_variants_are_refused_unless_unlocked():
+    """f16_variant 27 / 43 / 59 / 75 skip the DMA or the fragment reads on purpose (power breakdown,
+    DESIGN.md 3.2) and return wrong results: the library refuses them unless "ablations" is set."""
+    n = k = m = 512
+    a = np.ones((n, k), np.float16)
+    b = np.ones((k, m), np.float16)
+    try:
+        for v in (27, 43, 59, 75):
+            g.set_tuning("f16_variant", v)
+            with pytest.raises(g.MMError):
+                g.matmul_capi(a, b, "half")
+        g.set_tuning("ablations", 1)
+        g.set_tuning("f16_variant", 75)      # L2-resident sources: runs, result is not the product
+        c, _ = g.matmul_capi(a, b, "half")
+        assert c.shape == (n, m)
+    finally:
+        g.set_tuning("ablations", -1)
+        g.set_tuning("f16_variant", -1)
