@@ -22,7 +22,7 @@ if [ ! -d "$REF/kernel" ]; then
   exit 0
 fi
 case "$DT" in
-  float|int|unsigned) W=4;; double|long|"unsigned long") W=8;; short|"unsigned short") W=2;;
+  float|int|unsigned) W=4;; double|long|"unsigned long") W=8;; short|"unsigned short"|half) W=2;;
   char|"unsigned char"|uint8_t|int8_t) W=1;; *) echo "unsupported type $DT" >&2; exit 1;;
 esac
 NAME="${DT// /_}_${MAP}_${RED}_${TN}x${TM}_${PN}x${PM}"
@@ -43,6 +43,7 @@ sed -e "s/\${MM_DATA_WIDTH_\${MM_DATA_TYPE}}/$W/g" \
     "$REF/include/Config.h.in" > "$OUT/Config.h"
 CXX=${CXX:-g++}
 FLAGS="-std=c++17 -O2 -fPIC -pthread -DMM_DYNAMIC_SIZES -I$OUT -I$REF/include -I$HERE/hlslib_shim"
+if [ "$DT" = half ]; then FLAGS="$FLAGS -DMM_HALF_PRECISION -I$HERE/hlslib_shim/hlslib/xilinx"; fi   # CMakeLists.txt:110-112; hls_half.h is a Vitis include-path header
 $CXX $FLAGS -shared -o "$OUT/libmmkernel_ref.so" \
     "$REF/kernel/Compute.cpp" "$REF/kernel/Memory.cpp" "$REF/kernel/Top.cpp"
 $CXX $FLAGS -o "$OUT/TestSimulation" "$REF/test/TestSimulation.cpp" \

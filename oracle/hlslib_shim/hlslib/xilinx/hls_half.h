@@ -55,6 +55,10 @@ class half {
   half &operator*=(half o) { return *this = *this * o; }
   friend bool operator==(half a, half b) { return a.ToDouble() == b.ToDouble(); }
   friend bool operator!=(half a, half b) { return !(a == b); }
+  // exact matches for comparisons with integer literals (`diff != 0`, test/TestSimulation.cpp:84),
+  // which are otherwise ambiguous between half(int) and operator float()
+  friend bool operator==(half a, int b) { return a.ToDouble() == b; }
+  friend bool operator!=(half a, int b) { return a.ToDouble() != b; }
   friend bool operator<(half a, half b) { return a.ToDouble() < b.ToDouble(); }
   friend bool operator>(half a, half b) { return b < a; }
   friend bool operator<=(half a, half b) { return !(b < a); }

@@ -37,17 +37,21 @@ def main():
     subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "-s"], check=True, stdout=subprocess.DEVNULL)
     small = [(37, 32, 48), (1, 16, 16), (300, 64, 272)]
     checks = {}
-    for dtype, mp, rd in [("float", "Multiply", "Add"), ("int", "Multiply", "Add"), ("float", "Add", "Min")]:
+    # half: the reference's kernel accumulates in binary16 (Xilinx `half`; oracle/hlslib_shim/.../hls_half.h is
+    # an IEEE binary16 with round-to-nearest-even) -- the semantics RunHardware's hw_emu mode reproduces
+    for dtype, mp, rd in [("float", "Multiply", "Add"), ("int", "Multiply", "Add"), ("float", "Add", "Min"),
+                          ("half", "Multiply", "Add")]:
         if not _oracle.ref_available(dtype, mp, rd):
             print("skip (oracle/_ref not built):", dtype, mp, rd)
             continue
-        for (n, k, m) in small:
+        # half: the 64-byte bus is 32 elements, so K and M are multiples of 32 (host/RunHardware.cpp:50-61)
+        for (n, k, m) in ([(37, 32, 64), (1, 32, 32), (300, 64, 288)] if dtype == "half" else small):
             a, b = _oracle.fill(dtype, n, k, m)
             c = _oracle.ref_kernel(dtype, mp, rd, a, b)
             np.savez_compressed(os.path.join(HERE, f"ref_{dtype}_{mp}_{rd}_{n}x{k}x{m}.npz"), c=c,
                                 a_sha256=hashlib.sha256(a.tobytes()).hexdigest(),
                                 b_sha256=hashlib.sha256(b.tobytes()).hexdigest())
-        n, k, m = 513, 528, 528
+        n, k, m = (513, 544, 544) if dtype == "half" else (513, 528, 528)  # CMakeLists.txt:155-159 per bus width
         a, b = _oracle.fill(dtype, n, k, m)
         c = _oracle.ref_kernel(dtype, mp, rd, a, b)
         checks[f"{dtype}_{mp}_{rd}"] = {

@@ -163,7 +163,7 @@ def test_oracle_reproduces_reference_kernel_golden(path, dtype, mp, rd, shape):
 
 def test_oracle_reproduces_reference_ctest_shape_checksum():
     checks = json.load(open(os.path.join(GOLD, "ref_checksums.json")))
-    for cfg in ("float_Multiply_Add", "int_Multiply_Add"):
+    for cfg in ("float_Multiply_Add", "int_Multiply_Add", "half_Multiply_Add"):
         dtype, mp, rd = cfg.split("_")
         n, k, m = checks[cfg]["shape"]
         a, b = _oracle.fill(dtype, n, k, m)
