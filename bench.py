@@ -48,7 +48,11 @@ WORKLOADS = {
     "double": ("double", "Multiply", "Add", 16384, "mfma", 78.6),
     "minplus": ("float", "Add", "Min", 8192, "valu", 78.6),
     "uint8": ("uint8_t", "Multiply", "Add", 32768, "mfma", 5000.0),
+    # MM_PATH_SPLIT (opt-in): the same fp32 problem on the bf16 matrix cores, six bf16 MFMAs per 16-deep fp32
+    # multiply-add block -> the roof for ALGORITHMIC fp32 flops is the bf16 dense peak / 6
+    "float_split": ("float", "Multiply", "Add", 16384, "mfma", round(2500.0 / 6.0, 1)),
 }
+PATHS = {"float_split": 2}  # workload -> mm_path_t (default MM_PATH_AUTO)
 DTYPE_TAG = {"float": "f32", "half": "f16 (f32 accumulate)", "double": "f64", "uint8_t": "u8 (i32 accumulate)"}
 # Context for the two power-limited workloads (not a roof this file prices against: `peak` stays the
 # guide's dense MFMA peak): what the matrix cores sustain from registers alone, no LDS and no memory, on
@@ -119,11 +123,11 @@ def hbm_traffic_per_launch():
     return None, None
 
 
-def timed_steps(g, torch, a, b, c, dtype, map_op, reduce_op, steps, warmup, barrier):
+def timed_steps(g, torch, a, b, c, dtype, map_op, reduce_op, steps, warmup, barrier, path=0):
     """W untimed steps, barrier + synchronize, EXACTLY `steps` steps, synchronize + barrier.
     Returns (wall seconds of the timed region, sorted per-launch ms from events on the launch stream)."""
     def step():
-        g.matmul(a, b, dtype, map_op, reduce_op, out=c)
+        g.matmul(a, b, dtype, map_op, reduce_op, path=path, out=c)
     for _ in range(warmup):
         step()
     torch.cuda.synchronize()
@@ -169,21 +173,29 @@ def roofline_obj(dtype, roof, peak, rows, k, m, launch_ms):
 def extra_workloads(g, torch, dev, local_rank, steps=5):
     """The other single-GPU BASELINE configs, a few steps each, in the same process."""
     out = []
-    jobs = [("half", None), ("double", None), ("minplus", None), ("uint8", None), ("float", C5A_ROWS)]
+    jobs = [("half", None), ("double", None), ("minplus", None), ("uint8", None), ("float", C5A_ROWS), ("float_split", None)]
     for key, rows_override in jobs:
         dtype, map_op, reduce_op, size, roof, peak = WORKLOADS[key]
         rows = rows_override or size
         k = m = size
         try:
             a, b, c = alloc_fill(g, torch, dev, local_rank, dtype, rows, k, m, 2000 + len(out), 3000 + len(out))
-            elapsed, launch_ms = timed_steps(g, torch, a, b, c, dtype, map_op, reduce_op, steps, 2, lambda: None)
+            path = PATHS.get(key, 0)
+            elapsed, launch_ms = timed_steps(g, torch, a, b, c, dtype, map_op, reduce_op, steps, 2, lambda: None, path)
             value = 1e-9 * 2.0 * rows * k * m * steps / elapsed
-            out.append({"workload": f"{dtype} {rows}x{k}x{m} ({map_op},{reduce_op}) on 1 MI355X"
-                                    + ("; BASELINE configs[4]'s job without the split" if rows_override else ""),
-                        "kernel": g.kernel_name(g.make_config(dtype, map_op, reduce_op), rows, k, m),
-                        "dtype": DTYPE_TAG[dtype], "value": round(value, 1), "unit": "GOp/s", "steps": steps, "warmup": 2,
-                        "ms_per_step": round(1e3 * elapsed / steps, 4),
-                        "roofline": roofline_obj(dtype, roof, peak, rows, k, m, launch_ms)})
+            entry = {"workload": f"{dtype} {rows}x{k}x{m} ({map_op},{reduce_op}) on 1 MI355X"
+                                 + ("; BASELINE configs[4]'s job without the split" if rows_override else ""),
+                     "kernel": g.kernel_name(g.make_config(dtype, map_op, reduce_op, path), rows, k, m),
+                     "dtype": DTYPE_TAG[dtype], "value": round(value, 1), "unit": "GOp/s", "steps": steps, "warmup": 2,
+                     "ms_per_step": round(1e3 * elapsed / steps, 4),
+                     "roofline": roofline_obj(dtype, roof, peak, rows, k, m, launch_ms)}
+            if key == "float_split":
+                entry["workload"] += "; MM_PATH_SPLIT (opt-in), split + re-tile pre-pass inside the timed step"
+                entry["dtype"] = "f32 in/out; operands as 3 bf16 planes, 6 bf16 MFMA products per pair, f32 accumulate"
+                entry["roofline"]["peak_note"] = ("bf16 dense MFMA peak 2500 TFLOP/s / 6 MFMAs per fp32 multiply-add block; "
+                                                  "against the fp32 MFMA peak (157.3) the same number is "
+                                                  f"{round(entry['roofline']['achieved'] / 157.3, 3)}")
+            out.append(entry)
         except Exception as exc:  # an extra must never take the headline line down with it
             out.append({"workload": key, "error": repr(exc)})
         a = b = c = None
@@ -266,7 +278,8 @@ def main():
         """One timed region of the contract over the job of n_total rows; rank r owns row_slab(r)."""
         row0, rows = row_slab(n_total, world, rank)
         a, b, c = alloc_fill(g, torch, dev, local_rank, dtype, rows, k, m, seed_base + rank, 7)
-        elapsed, launch_ms = timed_steps(g, torch, a, b, c, dtype, map_op, reduce_op, args.steps, args.warmup, barrier)
+        elapsed, launch_ms = timed_steps(g, torch, a, b, c, dtype, map_op, reduce_op, args.steps, args.warmup, barrier,
+                                         PATHS.get(args.workload, 0))
         elapsed = max_over_ranks(elapsed)
         a = b = c = None
         torch.cuda.empty_cache()
@@ -322,7 +335,7 @@ def main():
             "data": "synthetic: uniform [1,10) (the reference generator's distribution), generated on device",
             "pct_of_mfma_peak": round(100.0 * value / 1e3 / (peak * world), 2),
             "config": {"workload": what,
-                       "kernel": g.kernel_name(g.make_config(dtype, map_op, reduce_op), rows, k, m),
+                       "kernel": g.kernel_name(g.make_config(dtype, map_op, reduce_op, PATHS.get(args.workload, 0)), rows, k, m),
                        "rows_total": n_total, "rows_per_gpu": rows},
             "roofline": rl,
         }

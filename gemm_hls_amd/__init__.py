@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libmm_gemm_amd.so")
 DTYPES = {"float": 0, "double": 1, "half": 2, "int8_t": 3, "uint8_t": 4, "int16_t": 5,
           "uint16_t": 6, "int": 7, "unsigned": 8, "long": 9, "unsigned long": 10}
 OPS = {"Add": 0, "Multiply": 1, "And": 2, "Min": 3, "Max": 4}
-PATH_AUTO, PATH_ORDERED = 0, 1
+PATH_AUTO, PATH_ORDERED, PATH_SPLIT = 0, 1, 2
 
 EXPORTS = ["mm_init", "mm_alloc", "mm_free", "mm_copy_to_device", "mm_copy_to_host",
            "mm_fill_device", "mm_gemm_launch", "mm_gemm_enqueue", "mm_gemm_multi_device",

@@ -87,9 +87,9 @@ mm_config_t default_cfg() {
 std::once_flag g_tuning_once;
 std::atomic<int> g_tuning[mm::TUNE_COUNT];
 const char *const kTuneName[mm::TUNE_COUNT] = {"f32_variant", "f64_variant", "f16_variant", "i8_variant", "band_rows",
-                                               "valu_variant", "ablations"};
+                                               "valu_variant", "split_variant", "ablations"};
 const char *const kTuneEnv[mm::TUNE_COUNT] = {"MM_F32_VARIANT", "MM_F64_VARIANT", "MM_F16_VARIANT", "MM_I8_VARIANT",
-                                              "MM_BAND_ROWS", "MM_VALU_VARIANT", "MM_ABLATIONS"};
+                                              "MM_BAND_ROWS", "MM_VALU_VARIANT", "MM_SPLIT_VARIANT", "MM_ABLATIONS"};
 void tuning_init() {
   for (int i = 0; i < mm::TUNE_COUNT; ++i) {
     const char *e = getenv(kTuneEnv[i]);
@@ -108,7 +108,7 @@ int check_device(int device) {
 bool valid_cfg(const mm_config_t *cfg) {
   return cfg && cfg->dtype >= MM_DTYPE_F32 && cfg->dtype <= MM_DTYPE_U64 && cfg->map_op >= MM_OP_ADD &&
          cfg->map_op <= MM_OP_MAX && cfg->reduce_op >= MM_OP_ADD && cfg->reduce_op <= MM_OP_MAX &&
-         (cfg->path == MM_PATH_AUTO || cfg->path == MM_PATH_ORDERED) &&
+         (cfg->path == MM_PATH_AUTO || cfg->path == MM_PATH_ORDERED || cfg->path == MM_PATH_SPLIT) &&
          (cfg->layout_a == MM_A_ROW_MAJOR || cfg->layout_a == MM_A_TRANSPOSED);
 }
 
@@ -122,11 +122,14 @@ int f32_variant_for(const mm::Problem &p) {
   return v >= 0 ? v : (p.a_transposed ? 8 : mm::mfma_f32_auto_variant(p));
 }
 
-enum Family { FAM_ORDERED, FAM_VALU_TILE, FAM_MFMA_F32, FAM_MFMA_F64, FAM_MFMA_F16, FAM_MFMA_I8, FAM_HALF_WIDE };
+enum Family { FAM_ORDERED, FAM_VALU_TILE, FAM_MFMA_F32, FAM_MFMA_F64, FAM_MFMA_F16, FAM_MFMA_I8, FAM_HALF_WIDE,
+              FAM_F32_SPLIT, FAM_NONE };
 
 Family choose(const mm_config_t &cfg, const mm::Problem &p) {
   if (cfg.path == MM_PATH_ORDERED) return FAM_ORDERED;
   const bool mul_add = cfg.map_op == MM_OP_MULTIPLY && cfg.reduce_op == MM_OP_ADD;
+  if (cfg.path == MM_PATH_SPLIT)  // an explicit request is never re-routed: fp32 (x,+) or nothing
+    return mul_add && cfg.dtype == MM_DTYPE_F32 && mm::mfma_f32_split_serves(p) ? FAM_F32_SPLIT : FAM_NONE;
   if (mul_add && cfg.dtype == MM_DTYPE_F32 && mm::mfma_f32_serves(p)) return FAM_MFMA_F32;
   if (mul_add && cfg.dtype == MM_DTYPE_F64 && mm::mfma_f64_serves(p)) return FAM_MFMA_F64;
   // half (x,+) keeps ONE numerical contract under AUTO (exact products, f32 accumulation, one
@@ -148,7 +151,10 @@ bool aligned16(const mm::Problem &p) {
 int dispatch(hipStream_t s, const mm_config_t &cfg, const mm::Problem &p) {
   if (p.n == 0 || p.m == 0) return MM_OK;  // nothing to write
   const Family fam = choose(cfg, p);
-  if (fam != FAM_ORDERED && fam != FAM_HALF_WIDE && !aligned16(p))
+  if (fam == FAM_NONE)
+    return fail(MM_ERR_UNSUPPORTED, "MM_PATH_SPLIT serves float (Multiply, Add) only (got dtype %d, map %d, reduce %d)",
+                (int)cfg.dtype, (int)cfg.map_op, (int)cfg.reduce_op);
+  if (fam != FAM_ORDERED && fam != FAM_HALF_WIDE && fam != FAM_F32_SPLIT && !aligned16(p))
     return fail(MM_ERR_BAD_ARGUMENT, "a, b and c must be 16-byte aligned for the fast path (got %p, %p, %p); "
                 "use an aligned allocation or MM_PATH_ORDERED", p.a, p.b, p.c);
   int e;
@@ -158,6 +164,7 @@ int dispatch(hipStream_t s, const mm_config_t &cfg, const mm::Problem &p) {
     case FAM_MFMA_F16: e = mm::launch_mfma_f16(s, p); break;
     case FAM_MFMA_I8: e = mm::launch_mfma_i8(s, p); break;
     case FAM_HALF_WIDE: e = mm::launch_half_wide(s, p); break;
+    case FAM_F32_SPLIT: e = mm::launch_mfma_f32_split(s, p, mm::tuning(mm::TUNE_SPLIT_VARIANT)); break;
     case FAM_VALU_TILE:
       e = mm::launch_valu_tile(s, cfg, p);
       if (e == mm::kErrNotSupported) e = mm::launch_ordered(s, cfg, p);  // still the GPU
@@ -494,7 +501,12 @@ void MatrixMultiplicationKernel(const void *a, const void *b, void *c, unsigned 
   }
 }
 
-int mm_config_supported(const mm_config_t *cfg) { return valid_cfg(cfg) ? 1 : 0; }
+int mm_config_supported(const mm_config_t *cfg) {
+  if (!valid_cfg(cfg)) return 0;
+  if (cfg->path == MM_PATH_SPLIT)
+    return cfg->dtype == MM_DTYPE_F32 && cfg->map_op == MM_OP_MULTIPLY && cfg->reduce_op == MM_OP_ADD;
+  return 1;
+}
 
 const char *mm_kernel_name(const mm_config_t *cfg, unsigned n, unsigned k, unsigned m) {
   if (!valid_cfg(cfg)) return "invalid";
@@ -505,6 +517,8 @@ const char *mm_kernel_name(const mm_config_t *cfg, unsigned n, unsigned k, unsig
     case FAM_MFMA_F16: return "mfma_f16";
     case FAM_MFMA_I8: return "mfma_i8";
     case FAM_HALF_WIDE: return "ordered_wide_f16";
+    case FAM_F32_SPLIT: return "mfma_f32_split_bf16x3";
+    case FAM_NONE: return "unsupported";
     case FAM_VALU_TILE: return "valu_tile";
     default: return "ordered";
   }
@@ -543,6 +557,12 @@ int mm_kernel_info(const mm_config_t *cfg, unsigned n, unsigned k, unsigned m, m
       r.tile_k = (k % 64 == 0 && k >= 256 && cfg->layout_a == MM_A_ROW_MAJOR) ? 64 : 128;
       r.inst_n = 32; r.inst_m = 32; r.inst_k = 32; r.ops_per_clk_per_cu = 8192.0;
       r.measured_issue_efficiency = r.tile_k == 64 ? 0.92 : 0.68;  // profiles/r02i_pmc_i8_32768.json / r01_pmc_i8.json
+      break;
+    case FAM_F32_SPLIT:
+      r.tile_n = 256; r.tile_m = 256; r.tile_k = 16; r.wavefronts = 8;
+      r.inst_n = 32; r.inst_m = 32; r.inst_k = 16;
+      r.ops_per_clk_per_cu = 4096.0 / 6.0;  // six bf16 MFMAs per fp32 multiply-add block
+      r.measured_issue_efficiency = 0.90;
       break;
     case FAM_VALU_TILE: {
       r.tile_n = 128; r.tile_m = 128; r.tile_k = 16; r.wavefronts = 4;

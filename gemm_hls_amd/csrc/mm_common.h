@@ -85,6 +85,9 @@ int launch_mfma_f32(hipStream_t s, const Problem &p, int variant);
 int launch_mfma_f64(hipStream_t s, const Problem &p);
 int launch_mfma_f16(hipStream_t s, const Problem &p);
 int launch_mfma_i8(hipStream_t s, const Problem &p);
+int launch_mfma_f32_split(hipStream_t s, const Problem &p, int variant);  // MM_PATH_SPLIT (mm_mfma_f32_split.hip)
+bool mfma_f32_split_serves(const Problem &p);
+size_t mfma_f32_split_workspace_bytes(const Problem &p);
 bool mfma_f32_serves(const Problem &p);
 bool mfma_f64_serves(const Problem &p);
 bool mfma_f16_serves(const Problem &p);
@@ -123,6 +126,7 @@ enum Tunable {
   TUNE_I8_VARIANT,       // MM_I8_VARIANT
   TUNE_BAND_ROWS,        // MM_BAND_ROWS    tile-rows per rasterisation band
   TUNE_VALU_VARIANT,     // MM_VALU_VARIANT 0 = synchronous valu_tile kernel, else (default) the DMA-staged one
+  TUNE_SPLIT_VARIANT,    // MM_SPLIT_VARIANT schedule / product count of the MM_PATH_SPLIT kernel (mm_mfma_f32_split.hip)
   TUNE_ABLATIONS,        // MM_ABLATIONS    1 = allow the variants that skip work on purpose (power breakdown
                          //                 measurements; they produce WRONG results and are refused otherwise)
   TUNE_COUNT

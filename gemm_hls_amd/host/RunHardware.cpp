@@ -17,6 +17,8 @@
 // of ... W" line, host/RunHardware.cpp:156-172,182-185 -- the board's own sensor through
 // librocm_smi64 / hwmon instead of the reference's PSU meter).
 // Environment: MM_GPUS=<g> splits the rows of C over g devices (no collective; default 1).
+//              MM_PATH=split runs "hw" through MM_PATH_SPLIT (float (Multiply, Add) builds only: fp32 on the
+//              bf16 matrix cores from three planes per operand, include/mm_gemm.h); anything else is refused.
 #include <chrono>
 #include <cstdlib>
 #include <iomanip>
@@ -112,8 +114,17 @@ int main(int argc, char **argv) {
   }
   const int gpus = std::getenv("MM_GPUS") ? std::max(1, std::atoi(std::getenv("MM_GPUS"))) : 1;
 
-  const mm_config_t cfg = {mmhost::DTypeOf<Data_t>::value, OperatorMap::code, OperatorReduce::code,
-                           emulation ? MM_PATH_ORDERED : MM_PATH_AUTO, kTransposedA ? MM_A_TRANSPOSED : MM_A_ROW_MAJOR};
+  mm_path_t path = emulation ? MM_PATH_ORDERED : MM_PATH_AUTO;
+  if (const char *want = std::getenv("MM_PATH")) {
+    if (std::string(want) == "split" && !emulation) {
+      path = MM_PATH_SPLIT;
+    } else if (std::string(want) != "auto") {
+      std::cerr << "MM_PATH must be \"auto\" or \"split\" (with hw); got \"" << want << "\"\n";
+      return 1;
+    }
+  }
+  const mm_config_t cfg = {mmhost::DTypeOf<Data_t>::value, OperatorMap::code, OperatorReduce::code, path,
+                           kTransposedA ? MM_A_TRANSPOSED : MM_A_ROW_MAJOR};
   const size_t count_a = (size_t)size_n * size_k, count_b = (size_t)size_k * size_m, count_c = (size_t)size_n * size_m;
 
   std::vector<Data_t> a, b, cRef, cTest;

@@ -56,8 +56,17 @@ typedef enum {
  *                    Naive does -- acc = identity; for k ascending: acc = Reduce(acc, Map(a,b)),
  *                    multiply and add NOT fused -- bit-identical to include/Utility.h:18-42
  *                    for every dtype; == RunHardware "hw_emu" (a slower, independently written
- *                    execution of the same contract on the same device). */
-typedef enum { MM_PATH_AUTO = 0, MM_PATH_ORDERED = 1 } mm_path_t;
+ *                    execution of the same contract on the same device).
+ *   MM_PATH_SPLIT    float (Multiply, Add) only, opt-in: fp32 operands split into three bf16
+ *                    planes (all 24 significand bits), six bf16 matrix-core products per
+ *                    element pair accumulated in fp32 -- each product good to ~2^-25, i.e. at
+ *                    least as fine as an fp32 multiply; 1.7x the fp32 matrix-core peak.  Any
+ *                    N, K, M and any element-aligned pointers; needs 6 bytes of stream-ordered
+ *                    workspace per element of A and B (hipMallocAsync on the launch stream).
+ *                    Inputs must be finite and below 2^127 in magnitude for the error bound
+ *                    to hold (an inf/nan operand still gives non-finite results, but +inf may become nan).  Any other
+ *                    configuration: MM_ERR_UNSUPPORTED.  RunHardware: MM_PATH=split with "hw". */
+typedef enum { MM_PATH_AUTO = 0, MM_PATH_ORDERED = 1, MM_PATH_SPLIT = 2 } mm_path_t;
 
 /* Layout of A: row-major N x K (default) or K x N == the reference's MM_TRANSPOSED_A
  * (CMakeLists.txt:30, include/Utility.h:31-35, kernel/Memory.cpp:205-261). */
@@ -179,7 +188,7 @@ typedef struct {
 int mm_kernel_info(const mm_config_t *cfg, unsigned size_n, unsigned size_k, unsigned size_m,
                    mm_kernel_info_t *info);
 /* Tuning knobs for sweeps and ablations ("f32_variant", "f64_variant", "f16_variant",
- * "i8_variant", "valu_variant", "band_rows"; -1 = the library's own choice; "ablations" = 1 unlocks the
+ * "i8_variant", "valu_variant", "split_variant", "band_rows"; -1 = the library's own choice; "ablations" = 1 unlocks the
  * measurement-only variants that skip work and therefore return wrong results).  Each is initialised ONCE from its
  * environment variable (MM_F32_VARIANT, ...) and changed only through this call afterwards; the
  * launch path never reads the environment.  No reference counterpart (the reference's tile sizes

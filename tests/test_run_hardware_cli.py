@@ -161,6 +161,22 @@ def test_run_hardware_multi_gpu_env_single_device():
     assert r.returncode == 0 and "Successfully verified." in r.stdout
 
 
+@pytest.mark.gpu
+def test_run_hardware_split_path_env():
+    """MM_PATH=split: the float (Multiply, Add) runner verifies through MM_PATH_SPLIT; other builds refuse it loudly."""
+    r = run(EXE, 513, 528, 528, "hw", "on", env={"MM_PATH": "split"})
+    assert r.returncode == 0 and "Successfully verified." in r.stdout, r.stdout + r.stderr
+    r = run(EXE, 4096, 4096, 4096, "hw", "off", env={"MM_PATH": "split"})
+    assert r.returncode == 0 and PERF_LINE.search(r.stdout)
+    r = run(os.path.join(ROOT, "bin", "RunHardware_int_Multiply_Add.exe"), 64, 64, 64, "hw", "on", env={"MM_PATH": "split"})
+    assert r.returncode == 1 and "MM_PATH_SPLIT" in r.stderr
+
+
+def test_run_hardware_rejects_unknown_path_env():
+    r = run(EXE, 64, 64, 64, "hw", "off", env={"MM_PATH": "fast"})
+    assert r.returncode == 1 and "MM_PATH must be" in r.stderr
+
+
 # ---- the other two host binaries of the reference: TestSimulation, PrintSpecifications ---------
 def test_print_specifications_cli_and_model():
     exe = os.path.join(ROOT, "bin", "PrintSpecifications.exe")

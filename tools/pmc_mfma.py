@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """MFMA utilisation, effective clock, wait breakdown, LDS conflicts and L2 hit rate of a kernel
 family from rocprofv3 PMC passes (each pass only --pmc + --kernel-trace, as gpurun requires).
-  python tools/pmc_mfma.py f32|f64|f16|minplus [--size 16384] [--out profiles/r01_pmc_f32.json]
+  python tools/pmc_mfma.py f32|f64|f16|minplus|uint8|split [--size 16384] [--out profiles/r01_pmc_f32.json]
 MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * 1024 SIMDs); effective clock =
 GRBM_GUI_ACTIVE / kernel duration (MI355X_MICROARCH.md, DVFS note)."""
 import argparse
@@ -21,7 +21,7 @@ PASSES = [
     ["SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_VMEM", "SQ_INSTS_VALU", "SQ_INSTS_LDS"],
 ]
 KERNEL = {"f32": "mfma_f32_kernel", "f64": "mfma_f64_kernel", "f16": "mfma_f16_", "minplus": "valu_tile_",
-          "uint8": "mfma_i8_"}
+          "uint8": "mfma_i8_", "split": "mfma_f32_split_kernel"}
 VARIANT = None  # --variant: pins the family's tuning knob (sweep.py --variants) for every pass
 
 

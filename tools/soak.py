@@ -30,8 +30,9 @@ noise = torch.empty(64 << 20, dtype=torch.float32, device=dev)
 na = torch.rand((2048, 2048), device=dev)
 nb = torch.rand((2048, 2048), device=dev)
 
-#      label          dtype      ops                  torch dtype     n     reps  knob          other variant
+#      label          dtype      ops                  torch dtype     n     reps  knob          other variant   [path]
 CASES = [
+    ("float split",  "float",   ("Multiply", "Add"), torch.float32, 8300, 100, "split_variant", 1, g.PATH_SPLIT),  # K = 8300: one flush + a ragged last slab
     ("float",        "float",   ("Multiply", "Add"), torch.float32, 8192, 60, "f32_variant", 3),     # 3: no flush -> not bitwise comparable
     ("half",         "half",    ("Multiply", "Add"), torch.float16, 16384, 150, "f16_variant", 0),
     ("half K%64=32", "half",    ("Multiply", "Add"), torch.float16, 8224, 100, "f16_variant", 0),    # plain ping-pong (K % 64 != 0)
@@ -41,7 +42,8 @@ CASES = [
     ("min-plus",     "float",   ("Add", "Min"), torch.float32, 8192, 60, "valu_variant", 0),
     ("int (x,+)",    "int",     ("Multiply", "Add"), torch.int32, 4096, 40, "valu_variant", 0),
 ]
-for label, dtype, ops, tdt, n, reps, knob, other in CASES:
+for label, dtype, ops, tdt, n, reps, knob, other, *rest in CASES:
+    path = rest[0] if rest else g.PATH_AUTO
     reps *= args.scale
     rows = n + 37                                        # ragged N on purpose
     a = torch.empty((rows, n), dtype=tdt, device=dev)
@@ -51,15 +53,15 @@ for label, dtype, ops, tdt, n, reps, knob, other in CASES:
     if dtype == "half":                                  # keep the sums finite: an all-inf result compares equal whatever happened
         a.mul_(2.0 ** -6)
         b.mul_(2.0 ** -6)
-    name = g.kernel_name(g.make_config(dtype, *ops), rows, n, n)
-    ref = g.matmul(a, b, dtype, *ops).clone()
+    name = g.kernel_name(g.make_config(dtype, *ops, path), rows, n, n)
+    ref = g.matmul(a, b, dtype, *ops, path=path).clone()
     torch.cuda.synchronize()
     if dtype in ("half", "float", "double"):
         assert bool(torch.isfinite(ref).all()), label
     same_as_other = None
     if knob is not None:
         g.set_tuning(knob, other)
-        alt = g.matmul(a, b, dtype, *ops)
+        alt = g.matmul(a, b, dtype, *ops, path=path)
         g.set_tuning(knob, -1)
         torch.cuda.synchronize()
         same_as_other = bool(torch.equal(alt.view(torch.uint8), ref.view(torch.uint8)))
@@ -73,7 +75,7 @@ for label, dtype, ops, tdt, n, reps, knob, other in CASES:
                 noise.mul_(1.0001)
             elif i % 3 == 2:
                 g.matmul(na, nb)
-        c = g.matmul(a, b, dtype, *ops)
+        c = g.matmul(a, b, dtype, *ops, path=path)
         if not torch.equal(c.view(torch.uint8), ref.view(torch.uint8)):
             bad += 1
     torch.cuda.synchronize()

@@ -38,13 +38,43 @@ def time_config(dtype, mp, rd, n, k, m, reps, path=g.PATH_AUTO):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["f32", "f64", "f16", "minplus", "uint8", "all"])
+    ap.add_argument("what", choices=["f32", "f64", "f16", "minplus", "uint8", "split", "all"])
     ap.add_argument("--sizes", default="4096,8192,16384")
     ap.add_argument("--variants", default="")
     ap.add_argument("--reps", type=int, default=5)
     args = ap.parse_args()
     sizes = [int(s) for s in args.sizes.split(",")]
-    if args.what == "f32":
+    if args.what == "split":   # MM_PATH_SPLIT next to the native fp32 kernel: ROUND-ROBIN launches (one of each per round) so
+        # that clock / thermal drift hits every candidate alike; "n" = the native kernel
+        variants = args.variants.split(",") if args.variants else ["n", "-1"]
+        L = g.lib()
+        for s in sizes:
+            ptrs = [ctypes.c_void_p() for _ in range(3)]
+            for p, cnt in zip(ptrs, (s * s, s * s, s * s)):
+                g._check(L.mm_alloc(0, cnt * 4, ctypes.byref(p)))
+            g._check(L.mm_fill_device(0, 0, ptrs[0], s * s, 1))
+            g._check(L.mm_fill_device(0, 0, ptrs[1], s * s, 2))
+            t = ctypes.c_double(0)
+            times = {v: [] for v in variants}
+            for rnd in range(args.reps + 1):
+                for v in variants:
+                    path = g.PATH_AUTO if v == "n" else g.PATH_SPLIT
+                    if v != "n":
+                        g.set_tuning("split_variant", int(v))
+                    cfg = g.make_config("float", path=path)
+                    g._check(L.mm_gemm_launch(0, ctypes.byref(cfg), ptrs[0], ptrs[1], ptrs[2], s, s, s, ctypes.byref(t)))
+                    if rnd:
+                        times[v].append(t.value)
+            for p in ptrs:
+                L.mm_free(0, p)
+            g.set_tuning("split_variant", -1)
+            for v in variants:
+                ts = sorted(times[v])
+                med = ts[len(ts) // 2]
+                tf = 2.0 * s ** 3 / med / 1e12
+                print(f"f32 {'native' if v == 'n' else 'split v' + v:12s} {s:6d}^3  med {med*1e3:9.3f} ms  {tf:7.2f} TF  "
+                      f"({100*tf/PEAK['float']:5.1f}% of 157.3)  best {2.0*s**3/ts[0]/1e12:7.2f} TF", flush=True)
+    elif args.what == "f32":
         variants = [int(v) for v in args.variants.split(",")] if args.variants else list(range(8))
         for v in variants:
             g.set_tuning("f32_variant", v)
