@@ -20,9 +20,14 @@
 #define MM_GEMM_NO_KERNEL_SYMBOL
 #include "HostConfig.h"
 
+// -DMM_DEFAULT_PATH=2 builds the shim over MM_PATH_SPLIT (float (Multiply, Add) only; include/mm_gemm.h)
+#ifndef MM_DEFAULT_PATH
+#define MM_DEFAULT_PATH MM_PATH_AUTO
+#endif
+
 namespace {
 void Run(const void *a, const void *b, void *c, unsigned size_n, unsigned size_k, unsigned size_m) {
-  const mm_config_t cfg = {mmhost::DTypeOf<Data_t>::value, OperatorMap::code, OperatorReduce::code, MM_PATH_AUTO,
+  const mm_config_t cfg = {mmhost::DTypeOf<Data_t>::value, OperatorMap::code, OperatorReduce::code, (mm_path_t)MM_DEFAULT_PATH,
                            kTransposedA ? MM_A_TRANSPOSED : MM_A_ROW_MAJOR};
   if (mm_gemm_host(&cfg, a, b, c, size_n, size_k, size_m) != MM_OK) {
     std::fprintf(stderr, "MatrixMultiplicationKernel failed: %s\n", mm_last_error());

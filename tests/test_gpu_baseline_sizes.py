@@ -220,7 +220,7 @@ def test_f64_f16_mixed_sign(dtype):
 @pytest.mark.parametrize("path", [g.PATH_AUTO, g.PATH_ORDERED], ids=["auto", "ordered"])
 def test_max_reduce_over_all_negative_values_uses_lowest_identity(dtype, path):
     """(Add, Max) / (Multiply, Max) where every mapped value is negative: the accumulator must be
-    seeded below them (identity() = lowest(), as Naive's seed behaves: DESIGN.md 3.3)."""
+    seeded below them (identity() = lowest(), as Naive's seed behaves: DESIGN.md 3.4)."""
     n, k, m = 130, 64, 96
     a, b = _oracle.fill(dtype, n, k, m)
     a = (-a).astype(a.dtype)
