@@ -22,10 +22,11 @@
 //     Cost: reads 4 B, writes 6 B per element of A and B -- O(N^2), ~1.5 % of the launch at 16384^3.
 //  2. GEMM: 256 x 256 tile per workgroup, 8 wavefronts (2 x 4, 128 x 64 each = 4 x 2 MFMA tiles),
 //     ring of three 48 KiB stages (A slab + B slab) filled by global_load_lds_dwordx4 two stages
-//     ahead, ONE barrier per stage, counted vmcnt.  Per stage a wavefront issues 48 MFMAs (1536
-//     cycles) against 18 fragment reads and 6 DMA pieces, so unlike the half kernel the LDS port is
-//     idle most of the time; fragment registers are double-buffered (A per row-tile, B per stage) so
-//     every read is issued one 12-MFMA group before its use.
+//     ahead, counted vmcnt.  Per stage a wavefront issues 48 MFMAs (1536 cycles) against 18 fragment
+//     reads and 6 DMA pieces.  Shipped schedule: ping-pong -- a load segment and a compute segment per
+//     stage, the two wavefronts of a SIMD one segment apart (pp_stage below).  Kept as variants: one
+//     barrier per stage with double-buffered fragment registers, reads ahead of / interleaved with
+//     the MFMA groups (stage below) -- the steps this kernel went through.
 //
 // The workspace (6 bytes per element of A and B, padded to whole blocks/slabs) is allocated
 // stream-ordered (hipMallocAsync / hipFreeAsync on the launch stream): no hidden global state, safe
@@ -117,7 +118,7 @@ __device__ __forceinline__ const char *uniform(const char *p) {
 // Ablations (WRONG results by construction; refused unless the "ablations" knob is set): bit 2: no DMA in the main
 // loop; bit 3: every workgroup streams block 0's slabs (all DMA traffic becomes L2 hits).
 // bit 4: fragment reads interleaved one by one with the MFMAs (sched_group_barrier) instead of issued in front of them;
-// bit 5: flush every 4128 k instead of every 8256.
+// bit 5: flush every 4128 k instead of every 8256; bit 6: ping-pong schedule (see pp_stage).
 // TERMS: 6 (default) or 3 (a1b2 + a2b1 + a1b1 only:
 // products to ~2^-16, the "three-pass" accuracy class; measurement knob, not dispatched by default).
 template <int VAR, int TERMS>
@@ -132,7 +133,10 @@ __global__ __launch_bounds__(GeoS::THREADS) void mfma_f32_split_kernel(const cha
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const unsigned lane = threadIdx.x & 63u;
   const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const unsigned wm = wave >> 2, wn = wave & 3u;  // 2 x 4 wavefront grid
+  constexpr bool PP = (VAR & 64) != 0;
+  const unsigned group = wave >> 2;               // PP: wavefronts w and w+4 share a SIMD and run one segment apart
+  const unsigned wm = PP ? (wave & 3u) >> 1 : wave >> 2;
+  const unsigned wn = PP ? (wave & 1u) * 2 + group : wave & 3u;  // 2 x 4 wavefront grid
   const unsigned lo = lane & 31u, hi = lane >> 5;
 
   const unsigned lin = xcd_remap(blockIdx.x, tiles_n * tiles_m);
@@ -255,15 +259,47 @@ __global__ __launch_bounds__(GeoS::THREADS) void mfma_f32_split_kernel(const cha
     }
   };
 
+  // Ping-pong form of a stage (VAR bit 6): a LOAD segment (all 18 fragments of the stage into registers, the 6 DMA
+  // pieces of stage s+2, the counted wait) and a COMPUTE segment (48 MFMAs, nothing else), a barrier after each.  The
+  // two wavefronts of a SIMD run one segment apart (group 1 starts one barrier late), so one is always in its compute
+  // segment: the matrix core never waits for a barrier round trip, a DMA issue or a fragment read.  Ring of 3 still
+  // suffices: stage s+2 goes into the buffer of stage s-1, whose last reader (group 1's load segment s-1) finished
+  // before the barrier that opens group 0's load segment s (tests/test_schedules.py replays this).
+  bf16x8 paf[TM][3];  // PP only: all A fragments of the stage (B fragments reuse bf[0])
+  auto pp_stage = [&](auto bufc, unsigned s) {
+    constexpr int BUF = decltype(bufc)::value;
+    const char *cur = smem + BUF * G::STAGE_BYTES;
+    read_b(cur, bf[0]);
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) read_a(cur, mi, paf[mi]);
+    if (!(VAR & 4)) issue(s + 2, (BUF + 2) % 3);
+    if constexpr (PIECES == 6) asm volatile("s_waitcnt vmcnt(6)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+    sync();
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) mac(mi, paf[mi], bf[0]);
+    __builtin_amdgcn_s_setprio(0);
+    sync();
+  };
+
   // ---- prologue: three stages in flight, stage 0 published, its first fragments in registers
+  const bool shifted = PP && group == 1;
   issue(0, 0);
   issue(1, 1);
-  issue(2, 2);
-  if constexpr (PIECES == 6) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  sync();
-  read_b(smem, bf[0]);
-  read_a(smem, 0, af[0]);
+  if constexpr (PP) {
+    if constexpr (PIECES == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    sync();
+    if (shifted) sync();  // group 1 runs one segment behind group 0
+  } else {
+    issue(2, 2);
+    if constexpr (PIECES == 6) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    sync();
+    read_b(smem, bf[0]);
+    read_a(smem, 0, af[0]);
+  }
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
   using I2 = std::integral_constant<int, 2>;
@@ -332,6 +368,15 @@ __global__ __launch_bounds__(GeoS::THREADS) void mfma_f32_split_kernel(const cha
   unsigned c0 = 0, cend = min(FC, slabs);
   for (;;) {
     for (unsigned s = c0; s < cend; s += 6) {
+      if constexpr (PP) {
+        pp_stage(I0{}, s);
+        if (s + 1 < cend) pp_stage(I1{}, s + 1);
+        if (s + 2 < cend) pp_stage(I2{}, s + 2);
+        if (s + 3 < cend) pp_stage(I0{}, s + 3);
+        if (s + 4 < cend) pp_stage(I1{}, s + 4);
+        if (s + 5 < cend) pp_stage(I2{}, s + 5);
+        continue;
+      }
       stage(I0{}, I0{}, s);
       if (s + 1 < cend) stage(I1{}, I1{}, s + 1);
       if (s + 2 < cend) stage(I2{}, I0{}, s + 2);
@@ -354,6 +399,7 @@ __global__ __launch_bounds__(GeoS::THREADS) void mfma_f32_split_kernel(const cha
     cend = min(cend + FC, slabs);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // trailing (dead) refills land before the LDS is released
+  if (PP && !shifted) sync();                         // group 0 executes as many barriers as group 1
   writeback(flushed, std::true_type{});
 }
 
@@ -377,10 +423,11 @@ size_t mfma_f32_split_workspace_bytes(const Problem &p) {
   return ((size_t)((p.n + 255) / 256) + (size_t)((p.m + 255) / 256)) * slabs * GeoS::SLAB_BYTES;
 }
 
-// variant (split_variant knob): -1 / 0 = default (6 products, interleaved fragment reads, flush every 8256 k);
-// otherwise a bit mask: 1 round-2 first schedule (fragment reads ahead of each MFMA group, s_setprio around the group),
-// 2 three products (planes 1 and 2 only), 4 no flush, 8 plain hipMalloc/hipFree workspace (diagnosis), 16 no DMA in the
-// main loop, 32 L2-resident sources (these two: ablations, see the kernel), 64 flush every 4128 k
+// variant (split_variant knob): -1 / 0 = default (6 products, ping-pong schedule, flush every 8256 k); otherwise a bit
+// mask: 1 first schedule of the round (one barrier per stage, fragment reads ahead of each MFMA group, s_setprio around
+// the group), 2 three products (planes 1 and 2 only), 4 no flush, 8 plain hipMalloc/hipFree workspace (diagnosis),
+// 16 no DMA in the main loop, 32 L2-resident sources (these two: ablations on the one-barrier schedule, see the kernel),
+// 64 flush every 4128 k, 128 one barrier per stage with the fragment reads interleaved between the MFMAs
 int launch_mfma_f32_split(hipStream_t s, const Problem &p, int variant) {
   using G = GeoS;
   const unsigned slabs = (p.k + 15) / 16;
@@ -416,13 +463,15 @@ int launch_mfma_f32_split(hipStream_t s, const Problem &p, int variant) {
   int rc = (int)hipGetLastError();
   if (rc == 0) {
     const char *bp = ws + a_bytes;
-    if (v & 2) rc = launch_gemm<16, 3>(s, ws, bp, p, slabs);
-    else if (v & 16) rc = launch_gemm<16 | 2 | 4, 6>(s, ws, bp, p, slabs);
+    if (v & 16) rc = launch_gemm<16 | 2 | 4, 6>(s, ws, bp, p, slabs);
     else if (v & 32) rc = launch_gemm<16 | 2 | 8, 6>(s, ws, bp, p, slabs);
-    else if (v & 4) rc = launch_gemm<16 | 2, 6>(s, ws, bp, p, slabs);
-    else if (v & 64) rc = launch_gemm<16 | 32, 6>(s, ws, bp, p, slabs);
     else if (v & 1) rc = launch_gemm<1, 6>(s, ws, bp, p, slabs);
-    else rc = launch_gemm<16, 6>(s, ws, bp, p, slabs);
+    else if ((v & 128) && (v & 4)) rc = launch_gemm<16 | 2, 6>(s, ws, bp, p, slabs);
+    else if (v & 128) rc = launch_gemm<16, 6>(s, ws, bp, p, slabs);
+    else if (v & 2) rc = launch_gemm<64, 3>(s, ws, bp, p, slabs);
+    else if (v & 4) rc = launch_gemm<64 | 2, 6>(s, ws, bp, p, slabs);
+    else if (v & 64) rc = launch_gemm<64 | 32, 6>(s, ws, bp, p, slabs);
+    else rc = launch_gemm<64, 6>(s, ws, bp, p, slabs);
   }
   hipError_t f;
   if (sync_alloc) { f = hipStreamSynchronize(s); (void)hipFree(ws); }

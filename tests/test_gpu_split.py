@@ -58,7 +58,7 @@ def test_split_keeps_all_six_products(k):
     assert _normwise(c, a, b) < 2.0 ** -22
 
 
-@pytest.mark.parametrize("variant", [-1, 1, 4, 64])
+@pytest.mark.parametrize("variant", [-1, 1, 4, 64, 128])
 @pytest.mark.parametrize("shape", [(513, 528, 528), (300, 1000, 70), (260, 4200, 300)], ids=lambda s: "x".join(map(str, s)))
 def test_split_mixed_sign_no_worse_than_the_fp32_kernels(shape, variant):
     """Mixed signs and a few entries 10^4 larger / smaller than the rest (exponents differ inside a fragment): the
@@ -95,6 +95,20 @@ def test_split_flush_chunks_are_deterministic_and_bound_the_drift(variant):
     c1, _ = g.matmul_capi(a, b, path=g.PATH_SPLIT)
     e, e1 = np.max(np.abs(c - exact) / exact), np.max(np.abs(c1 - exact) / exact)
     assert e < 3e-6 and e <= e1 * 1.25, (e, e1)
+
+
+@pytest.mark.parametrize("shape", [(513, 528, 528), (300, 8300, 272), (257, 17, 255)], ids=lambda s: "x".join(map(str, s)))
+def test_split_schedules_are_bit_identical(shape):
+    """Every schedule of the six-product kernel issues the same MFMAs on the same operands in the same order per
+    accumulator: ping-pong (default), one barrier per stage with reads ahead (1) / interleaved (128) must agree bit
+    for bit."""
+    n, k, m = shape
+    a, b = _oracle.fill("float", n, k, m)
+    ref, _ = g.matmul_capi(a, b, path=g.PATH_SPLIT)
+    for variant in (1, 128):
+        g.set_tuning("split_variant", variant)
+        c, _ = g.matmul_capi(a, b, path=g.PATH_SPLIT)
+        assert np.array_equal(c, ref), variant
 
 
 def test_split_three_product_variant_is_the_coarser_class():

@@ -137,6 +137,54 @@ def test_pingpong_full_line_a_requests(slabs):
     check(waves, buffer_of)
 
 
+@pytest.mark.parametrize("slabs", [1, 2, 3, 7, 12, 31])
+def test_split_kernel_one_barrier_per_stage(slabs):
+    """mfma_f32_split_kernel, default schedule: ring of 3 stages, 6 pieces per wave per stage, three stages issued in
+    the prologue; per stage: reads of this stage, vmcnt(6), barrier, refill of this stage's buffer with stage s+3,
+    reads of the first fragments of stage s+1."""
+    waves = []
+    for _ in range(8):
+        w = Wave()
+        for s in range(3):
+            w.issue(s, 6)
+        w.wait_vmcnt(12)
+        w.barrier()
+        w.read(0)
+        for s in range(slabs):
+            w.read(s)
+            w.wait_vmcnt(6)
+            w.barrier()
+            w.issue(s + 3, 6)
+            w.read(s + 1)              # B fragments and the first A fragments of the next stage
+        waves.append(w)
+    check(waves, lambda st: st % 3)
+
+
+@pytest.mark.parametrize("slabs", [1, 2, 3, 7, 12, 31])
+def test_split_kernel_pingpong_ring_of_three(slabs):
+    """mfma_f32_split_kernel, ping-pong schedule: two stages issued in the prologue; per stage a load segment (reads
+    of stage s, DMA of stage s+2 into the buffer of stage s-1, vmcnt(6)), barrier, compute segment, barrier; group 1
+    one barrier behind group 0."""
+    waves = []
+    for group in (0, 1):
+        w = Wave()
+        w.issue(0, 6)
+        w.issue(1, 6)
+        w.wait_vmcnt(6)
+        w.barrier()
+        if group == 1:
+            w.barrier()
+        for s in range(slabs):
+            w.read(s)
+            w.issue(s + 2, 6)
+            w.wait_vmcnt(6)
+            w.barrier()
+            w.barrier()
+        waves.append(w)
+    check(waves, lambda st: st % 3)
+    assert waves[1].epoch - waves[0].epoch == 1
+
+
 @pytest.mark.parametrize("slabs", [1, 2, 3, 9])
 def test_valu_tile_dma_double_buffer(slabs):
     """valu_tile_dma_kernel: ring of 2, per slab: vmcnt(0), barrier, issue the next slab, compute this one."""

@@ -32,7 +32,7 @@ nb = torch.rand((2048, 2048), device=dev)
 
 #      label          dtype      ops                  torch dtype     n     reps  knob          other variant   [path]
 CASES = [
-    ("float split",  "float",   ("Multiply", "Add"), torch.float32, 8300, 100, "split_variant", 1, g.PATH_SPLIT),  # K = 8300: one flush + a ragged last slab
+    ("float split",  "float",   ("Multiply", "Add"), torch.float32, 8300, 100, "split_variant", 128, g.PATH_SPLIT),  # K = 8300: one flush + a ragged last slab
     ("float",        "float",   ("Multiply", "Add"), torch.float32, 8192, 60, "f32_variant", 3),     # 3: no flush -> not bitwise comparable
     ("half",         "half",    ("Multiply", "Add"), torch.float16, 16384, 150, "f16_variant", 0),
     ("half K%64=32", "half",    ("Multiply", "Add"), torch.float16, 8224, 100, "f16_variant", 0),    # plain ping-pong (K % 64 != 0)
