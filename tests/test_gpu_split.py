@@ -177,6 +177,15 @@ def test_split_non_finite_operands_stay_non_finite():
     assert np.max(np.abs(c[keep] - exact) / exact) < 2e-6
 
 
+def test_split_through_the_multi_device_driver():
+    """mm_gemm_multi_device with path = MM_PATH_SPLIT: every device packs its own row slab of A and all of B."""
+    n, k, m = 300, 200, 272
+    a, b = _oracle.fill("float", n, k, m)
+    c1, _ = g.matmul_capi(a, b, path=g.PATH_SPLIT)
+    cm, t = g.matmul_host(a, b, path=g.PATH_SPLIT, devices=1)
+    assert np.array_equal(c1, cm) and t > 0
+
+
 def test_split_refuses_other_configurations():
     a, b = _oracle.fill("int", 32, 32, 32)
     with pytest.raises(g.MMError, match="MM_PATH_SPLIT"):

@@ -23,7 +23,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 WHAT = {"f32": ("mfma_f32_kernel", 4, "float"), "f16": ("mfma_f16_", 2, "half"), "f64": ("mfma_f64_kernel", 8, "double"),
-        "uint8": ("mfma_i8_", 1, "uint8_t"), "minplus": ("valu_tile_", 4, "float (Add,Min)")}
+        "uint8": ("mfma_i8_", 1, "uint8_t"), "minplus": ("valu_tile_", 4, "float (Add,Min)"),
+        "split": ("mfma_f32_split_kernel", 4, "float via MM_PATH_SPLIT (GEMM kernel only; the pre-pass moves 10 B per element of A and B on top)")}
 
 
 def run_pass(counter, size, workdir, what="f32", variant=None):
