@@ -212,3 +212,21 @@ def test_split_full_size_sampled_rows():
     assert rel < 4e-6, rel
     native = g.matmul(ta, tb)
     assert ((c - native).abs() / native).max().item() < 1e-5
+
+
+def test_split_c5a_shape_offsets_beyond_4gib():
+    """65536 x 16384 x 16384 (BASELINE configs[4] on one GPU): 6 GiB of packed A, C offsets past 4 GiB."""
+    import torch
+    n, k = 65536, 16384
+    ta = torch.empty((n, k), dtype=torch.float32, device="cuda")
+    tb = torch.empty((k, k), dtype=torch.float32, device="cuda")
+    g._check(g.lib().mm_fill_device(0, g.DTYPES["float"], ta.data_ptr(), ta.numel(), 5))
+    g._check(g.lib().mm_fill_device(0, g.DTYPES["float"], tb.data_ptr(), tb.numel(), 6))
+    c = g.matmul(ta, tb, path=g.PATH_SPLIT)
+    rows = [0, 255, 256, 16383, 16384, 40000, 65279, 65280, n - 1]
+    exact = ta[rows].double() @ tb.double()
+    rel = ((c[rows].double() - exact).abs() / exact).max().item()
+    assert rel < 4e-6, rel
+    # a slab computed alone equals the same rows of the full product, bitwise (same tiles, same chunking)
+    part = g.matmul(ta[32768:32768 + 512], tb, path=g.PATH_SPLIT)
+    assert torch.equal(part, c[32768:32768 + 512])
