@@ -243,6 +243,22 @@ int mm_free(int device, void *device_ptr) {
   return MM_OK;
 }
 
+int mm_release_workspace(int device) {
+  int rc = check_device(device);
+  if (rc) return rc;
+  hipMemPool_t pool;
+  MM_HIP(hipSetDevice(device));
+  MM_HIP(hipDeviceGetDefaultMemPool(&pool, device));
+  // the launch path raised the pool's release threshold so that freed workspace stays cached; drop it to 0 for
+  // the duration of a synchronisation (which is when the runtime releases), trim, and raise it again
+  unsigned long long none = 0, keep = ~0ull;
+  MM_HIP(hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &none));
+  MM_HIP(hipDeviceSynchronize());
+  MM_HIP(hipMemPoolTrimTo(pool, 0));
+  MM_HIP(hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep));
+  return MM_OK;
+}
+
 int mm_copy_to_device(int device, void *dst, const void *src, size_t bytes) {
   int rc = check_device(device);
   if (rc) return rc;

@@ -64,8 +64,9 @@ typedef enum {
  *                    N, K, M and any element-aligned pointers; needs 6 bytes of stream-ordered
  *                    workspace per element of A and B (hipMallocAsync on the launch stream).
  *                    Inputs must be finite and below 2^127 in magnitude for the error bound
- *                    to hold (an inf/nan operand still gives non-finite results, but +inf may become nan).  Any other
- *                    configuration: MM_ERR_UNSUPPORTED.  RunHardware: MM_PATH=split with "hw". */
+ *                    to hold (an inf/nan operand still gives non-finite results, but +inf may
+ *                    become nan).  Any other configuration: MM_ERR_UNSUPPORTED.  RunHardware:
+ *                    MM_PATH=split with "hw".  See mm_release_workspace(). */
 typedef enum { MM_PATH_AUTO = 0, MM_PATH_ORDERED = 1, MM_PATH_SPLIT = 2 } mm_path_t;
 
 /* Layout of A: row-major N x K (default) or K x N == the reference's MM_TRANSPOSED_A
@@ -101,6 +102,11 @@ int mm_alloc(int device, size_t bytes, void **device_ptr);
 int mm_free(int device, void *device_ptr);
 
 /* buffer.CopyFromHost / CopyToHost (RunHardware.cpp:142-144,189).  Blocking. */
+/* MM_PATH_SPLIT keeps its workspace (6 bytes per element of A and B of the largest launch so far) cached in
+ * the device's default stream-ordered memory pool between launches.  This waits for the device and hands
+ * that memory back to the driver; the next MM_PATH_SPLIT launch allocates again. */
+int mm_release_workspace(int device);
+
 int mm_copy_to_device(int device, void *device_dst, const void *host_src, size_t bytes);
 int mm_copy_to_host(int device, void *host_dst, const void *device_src, size_t bytes);
 

@@ -285,3 +285,29 @@ def test_ablation_variants_are_refused_unless_unlocked():
     finally:
         g.set_tuning("ablations", -1)
         g.set_tuning("f16_variant", -1)
+
+
+@pytest.mark.parametrize("path_name", ["auto", "split"])
+def test_enqueue_is_capturable_into_a_hip_graph(path_name):
+    """mm_gemm_enqueue issues only stream-ordered work (kernels; for MM_PATH_SPLIT also hipMallocAsync / hipFreeAsync),
+    so a launch-bound loop of small products can be captured once and replayed as a hipGraph (here through torch's
+    graph capture, which puts its capture stream in hipStreamCaptureModeGlobal)."""
+    import torch
+    path = g.PATH_SPLIT if path_name == "split" else g.PATH_AUTO
+    n, k, m = 384, 256, 320
+    a, b = _oracle.fill("float", n, k, m)
+    ta, tb = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+    outs = [torch.zeros((n, m), dtype=torch.float32, device="cuda") for _ in range(4)]
+    want = g.matmul(ta, tb, path=path).clone()      # also warms up: function attributes, pool configuration
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        for o in outs:
+            g.matmul(ta, tb, path=path, out=o)
+    for o in outs:
+        o.zero_()
+    for _ in range(3):
+        graph.replay()
+    torch.cuda.synchronize()
+    for o in outs:
+        assert torch.equal(o, want)

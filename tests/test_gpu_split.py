@@ -186,6 +186,31 @@ def test_split_through_the_multi_device_driver():
     assert np.array_equal(c1, cm) and t > 0
 
 
+def test_release_workspace_returns_the_pool_memory_and_the_path_keeps_working():
+    import torch
+    hip = ctypes.CDLL("libamdhip64.so")   # the runtime this process already uses
+
+    def reserved_mib():
+        pool, v = ctypes.c_void_p(), ctypes.c_uint64(0)
+        assert hip.hipDeviceGetDefaultMemPool(ctypes.byref(pool), 0) == 0
+        assert hip.hipMemPoolGetAttribute(pool, 5, ctypes.byref(v)) == 0   # hipMemPoolAttrReservedMemCurrent
+        return v.value >> 20
+
+    n = 2048
+    a, b = _oracle.fill("float", n, 256, n)
+    c0, _ = g.matmul_capi(a, b, path=g.PATH_SPLIT)
+    big = torch.empty((8192, 8192), dtype=torch.float32, device="cuda").uniform_(1, 10)
+    g.matmul(big, big, path=g.PATH_SPLIT)          # 2 x 8192^2 x 6 B = 768 MiB of workspace now sit in the pool
+    torch.cuda.synchronize()
+    assert reserved_mib() >= 768
+    g._check(g.lib().mm_release_workspace(0))
+    assert reserved_mib() == 0
+    c1, _ = g.matmul_capi(a, b, path=g.PATH_SPLIT)
+    assert np.array_equal(c0, c1)
+    with pytest.raises(g.MMError):
+        g._check(g.lib().mm_release_workspace(99))
+
+
 def test_split_refuses_other_configurations():
     a, b = _oracle.fill("int", 32, 32, 32)
     with pytest.raises(g.MMError, match="MM_PATH_SPLIT"):
