@@ -575,7 +575,8 @@ int mm_kernel_info(const mm_config_t *cfg, unsigned n, unsigned k, unsigned m, m
       r.measured_issue_efficiency = r.tile_k == 64 ? 0.92 : 0.68;  // profiles/r02i_pmc_i8_32768.json / r01_pmc_i8.json
       break;
     case FAM_F32_SPLIT:
-      r.tile_n = 256; r.tile_m = 256; r.tile_k = 16; r.wavefronts = 8;
+      r.tile_n = r.tile_m = (unsigned)mm::mfma_f32_split_tile(p, mm::tuning(mm::TUNE_SPLIT_VARIANT));
+      r.tile_k = 16; r.wavefronts = r.tile_n == 256 ? 8 : 4;
       r.inst_n = 32; r.inst_m = 32; r.inst_k = 16;
       r.ops_per_clk_per_cu = 4096.0 / 6.0;  // six bf16 MFMAs per fp32 multiply-add block
       r.measured_issue_efficiency = 0.90;

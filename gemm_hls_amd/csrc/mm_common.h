@@ -88,6 +88,7 @@ int launch_mfma_i8(hipStream_t s, const Problem &p);
 int launch_mfma_f32_split(hipStream_t s, const Problem &p, int variant);  // MM_PATH_SPLIT (mm_mfma_f32_split.hip)
 bool mfma_f32_split_serves(const Problem &p);
 size_t mfma_f32_split_workspace_bytes(const Problem &p);
+int mfma_f32_split_tile(const Problem &p, int variant);  // 256 or 128
 bool mfma_f32_serves(const Problem &p);
 bool mfma_f64_serves(const Problem &p);
 bool mfma_f16_serves(const Problem &p);

@@ -42,15 +42,28 @@ using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
-struct GeoS {
-  static constexpr int BM = 256, BN = 256, BK = 16, NS = 3, THREADS = 512;
-  static constexpr int TM = 4, TN = 2;                       // 128 x 64 per wavefront
+// Packed global layout (both operands, always): [256-row block][16-k slab][plane 3][fragment 8][lane 64][8 bf16]
+struct Packed {
   static constexpr int FRAG_BYTES = 64 * 16;                 // one MFMA operand: 64 lanes x 8 bf16
   static constexpr int PLANE_BYTES = 8 * FRAG_BYTES;         // 256 rows x 16 k of one plane
   static constexpr int SLAB_BYTES = 3 * PLANE_BYTES;         // 24 KiB: one k slab of one block, three planes
-  static constexpr int STAGE_BYTES = 2 * SLAB_BYTES;         // A slab + B slab
-  static constexpr int LDS_BYTES = NS * STAGE_BYTES;         // 144 KiB
 };
+// Tile geometries of the GEMM kernel.  FR = fragments (32-row groups) of a tile side; the LDS image of a stage is
+// [A: plane][FR fragments] [B: plane][FR fragments], i.e. the packed layout restricted to the tile's fragments.
+template <int FR_, int WM_, int WN_, int TM_>
+struct GeoT {
+  static constexpr int FR = FR_, BM = 32 * FR_, BN = 32 * FR_, WM = WM_, WN = WN_, THREADS = 64 * WM_ * WN_;
+  static constexpr int TM = TM_, TN = 2, NS = 3;
+  static_assert(WM * TM == FR && WN * TN == FR && WM * WN == FR, "one wavefront per fragment and per DMA piece");
+  static constexpr int FRAG_BYTES = Packed::FRAG_BYTES;
+  static constexpr int PLANE_BYTES = FR * FRAG_BYTES;        // in LDS
+  static constexpr int SLAB_BYTES = 3 * PLANE_BYTES;
+  static constexpr int STAGE_BYTES = 2 * SLAB_BYTES;         // A slab + B slab
+  static constexpr int LDS_BYTES = NS * STAGE_BYTES;
+  static constexpr int HALVES = 8 / FR;                      // tiles per packed 256-row block
+};
+using GeoS = GeoT<8, 2, 4, 4>;    // 256 x 256, 8 wavefronts of 128 x 64, 144 KiB LDS: one workgroup per CU
+using GeoS128 = GeoT<4, 2, 2, 2>; // 128 x 128, 4 wavefronts of 64 x 64, 72 KiB LDS: two workgroups per CU (mid-size problems)
 
 // ---- step 1: split + re-tile -----------------------------------------------------------------------
 __device__ __forceinline__ void split3(float x, __bf16 &p1, __bf16 &p2, __bf16 &p3) {
@@ -100,10 +113,10 @@ __global__ __launch_bounds__(512) void split_pack_kernel(const float *__restrict
     split3(x[e], a, b, c);
     p1[e] = a; p2[e] = b; p3[e] = c;
   }
-  char *out = dst + ((size_t)blk * slabs + slab) * GeoS::SLAB_BYTES + frag * GeoS::FRAG_BYTES + lane * 16;
+  char *out = dst + ((size_t)blk * slabs + slab) * Packed::SLAB_BYTES + frag * Packed::FRAG_BYTES + lane * 16;
   *(bf16x8 *)(out) = p1;
-  *(bf16x8 *)(out + GeoS::PLANE_BYTES) = p2;
-  *(bf16x8 *)(out + 2 * GeoS::PLANE_BYTES) = p3;
+  *(bf16x8 *)(out + Packed::PLANE_BYTES) = p2;
+  *(bf16x8 *)(out + 2 * Packed::PLANE_BYTES) = p3;
 }
 
 // a pointer every lane agrees on, in scalar registers (the DMA instruction takes its base from an SGPR pair)
@@ -121,22 +134,22 @@ __device__ __forceinline__ const char *uniform(const char *p) {
 // bit 5: flush every 4128 k instead of every 8256; bit 6: ping-pong schedule (see pp_stage).
 // TERMS: 6 (default) or 3 (a1b2 + a2b1 + a1b1 only:
 // products to ~2^-16, the "three-pass" accuracy class; measurement knob, not dispatched by default).
-template <int VAR, int TERMS>
-__global__ __launch_bounds__(GeoS::THREADS) void mfma_f32_split_kernel(const char *__restrict__ Ap,
+template <int VAR, int TERMS, class G = GeoS>
+__global__ __launch_bounds__(G::THREADS) void mfma_f32_split_kernel(const char *__restrict__ Ap,
                                                                          const char *__restrict__ Bp,
                                                                          float *__restrict__ C, unsigned N, unsigned M,
                                                                          unsigned slabs, unsigned tiles_n,
                                                                          unsigned tiles_m, unsigned kBand) {
-  using G = GeoS;
   constexpr int TM = G::TM, TN = G::TN;
   constexpr int NP = TERMS == 6 ? 3 : 2;  // planes read
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const unsigned lane = threadIdx.x & 63u;
   const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   constexpr bool PP = (VAR & 64) != 0;
+  static_assert(!PP || G::THREADS == 512, "the ping-pong schedule pairs wavefronts w and w+4 of one workgroup");
   const unsigned group = wave >> 2;               // PP: wavefronts w and w+4 share a SIMD and run one segment apart
-  const unsigned wm = PP ? (wave & 3u) >> 1 : wave >> 2;
-  const unsigned wn = PP ? (wave & 1u) * 2 + group : wave & 3u;  // 2 x 4 wavefront grid
+  const unsigned wm = PP ? (wave & 3u) >> 1 : wave / G::WN;
+  const unsigned wn = PP ? (wave & 1u) * 2 + group : wave % G::WN;  // WM x WN wavefront grid
   const unsigned lo = lane & 31u, hi = lane >> 5;
 
   const unsigned lin = xcd_remap(blockIdx.x, tiles_n * tiles_m);
@@ -144,19 +157,22 @@ __global__ __launch_bounds__(GeoS::THREADS) void mfma_f32_split_kernel(const cha
   const unsigned rows_in_band = min(kBand, tiles_n - band * kBand);
   const unsigned tile_r = band * kBand + within % rows_in_band, tile_c = within / rows_in_band;
 
-  // ---- DMA: a stage is two linear 24 KiB copies; wavefront w moves KiB w, w+8, w+16 of each
+  // ---- DMA: wavefront w moves fragment w of each plane of the tile's A slab and B slab (1 KiB pieces: source plane
+  // stride 8 KiB in the packed layout, LDS plane stride FR KiB); a 128-row tile is one half of a packed 256-row block
   const unsigned voff0 = wave * 1024 + lane * 16, voff1 = voff0 + 8 * 1024, voff2 = voff0 + 16 * 1024;
-  const char *a_base = Ap + ((VAR & 8) ? 0 : (size_t)tile_r * slabs * G::SLAB_BYTES);
-  const char *b_base = Bp + ((VAR & 8) ? 0 : (size_t)tile_c * slabs * G::SLAB_BYTES);
+  const char *a_base = Ap + ((VAR & 8) ? 0 : (size_t)(tile_r / G::HALVES) * slabs * Packed::SLAB_BYTES +
+                                                 (tile_r % G::HALVES) * G::FR * Packed::FRAG_BYTES);
+  const char *b_base = Bp + ((VAR & 8) ? 0 : (size_t)(tile_c / G::HALVES) * slabs * Packed::SLAB_BYTES +
+                                                 (tile_c % G::HALVES) * G::FR * Packed::FRAG_BYTES);
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
   auto issue = [&](unsigned slab, unsigned buf) {
     const unsigned sl = min(slab, slabs - 1);  // past the end: harmless re-fetch into a dead buffer
-    const char *ap = uniform(a_base + (size_t)sl * G::SLAB_BYTES), *bp = uniform(b_base + (size_t)sl * G::SLAB_BYTES);
+    const char *ap = uniform(a_base + (size_t)sl * Packed::SLAB_BYTES), *bp = uniform(b_base + (size_t)sl * Packed::SLAB_BYTES);
     const unsigned la = lds0 + buf * G::STAGE_BYTES + wave * 1024, lb = la + G::SLAB_BYTES;
     unsigned keep;
 #define MM_PIECE(vo, sb, la) "s_mov_b32 m0, " la "\n\ts_nop 0\n\tglobal_load_lds_dwordx4 " vo ", " sb "\n\t"
     if constexpr (NP == 3) {
-      const unsigned la1 = la + 8 * 1024, la2 = la + 16 * 1024, lb1 = lb + 8 * 1024, lb2 = lb + 16 * 1024;
+      const unsigned la1 = la + G::PLANE_BYTES, la2 = la + 2 * G::PLANE_BYTES, lb1 = lb + G::PLANE_BYTES, lb2 = lb + 2 * G::PLANE_BYTES;
       asm volatile("s_mov_b32 %0, m0\n\t" MM_PIECE("%1", "%4", "%6") MM_PIECE("%2", "%4", "%7") MM_PIECE("%3", "%4", "%8")
                        MM_PIECE("%1", "%5", "%9") MM_PIECE("%2", "%5", "%10") MM_PIECE("%3", "%5", "%11") "s_mov_b32 m0, %0"
                    : "=&s"(keep)
@@ -164,7 +180,7 @@ __global__ __launch_bounds__(GeoS::THREADS) void mfma_f32_split_kernel(const cha
                      "s"(lb2)
                    : "memory");
     } else {  // planes 1 and 2 only: 16 KiB per operand, wavefront w moves KiB w and w+8
-      const unsigned la1 = la + 8 * 1024, lb1 = lb + 8 * 1024;
+      const unsigned la1 = la + G::PLANE_BYTES, lb1 = lb + G::PLANE_BYTES;
       asm volatile("s_mov_b32 %0, m0\n\t" MM_PIECE("%1", "%3", "%5") MM_PIECE("%2", "%3", "%6") MM_PIECE("%1", "%4", "%7")
                        MM_PIECE("%2", "%4", "%8") "s_mov_b32 m0, %0"
                    : "=&s"(keep)
@@ -220,17 +236,16 @@ __global__ __launch_bounds__(GeoS::THREADS) void mfma_f32_split_kernel(const cha
   auto stage = [&](auto bufc, auto parc, unsigned s) {
     constexpr int BUF = decltype(bufc)::value, PAR = decltype(parc)::value;
     const char *cur = smem + BUF * G::STAGE_BYTES, *nxt = smem + ((BUF + 1) % 3) * G::STAGE_BYTES;
-    read_a(cur, 1, af[1]);
-    mac(0, af[0], bf[PAR]);
-    read_a(cur, 2, af[0]);
-    mac(1, af[1], bf[PAR]);
-    read_a(cur, 3, af[1]);
-    mac(2, af[0], bf[PAR]);
+#pragma unroll
+    for (int mi = 0; mi + 1 < TM; ++mi) {   // row-tile mi multiplies while row-tile mi+1's fragments arrive
+      read_a(cur, mi + 1, af[(mi + 1) & 1]);
+      mac(mi, af[mi & 1], bf[PAR]);
+    }
     if constexpr (VAR & 16) {  // one fragment read between MFMAs instead of three ahead of a group: the 8 wavefronts of a
                                // workgroup run in step after a barrier, and 8 x 3 (or 8 x 9) simultaneous 1 KiB reads
                                // queue on the 128 B/clk LDS port while instruction issue -- MFMAs included -- waits
 #pragma unroll
-      for (int grp = 0; grp < 3; ++grp) {
+      for (int grp = 0; grp + 1 < TM; ++grp) {
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
@@ -246,7 +261,7 @@ __global__ __launch_bounds__(GeoS::THREADS) void mfma_f32_split_kernel(const cha
     if (!(VAR & 4)) issue(s + 3, BUF);
     read_b(nxt, bf[PAR ^ 1]);
     read_a(nxt, 0, af[0]);
-    mac(3, af[1], bf[PAR]);
+    mac(TM - 1, af[(TM - 1) & 1], bf[PAR]);
     if constexpr (VAR & 16) {
       constexpr int READS = (TN + 1) * NP, MFMAS = 2 * TERMS;
 #pragma unroll
@@ -310,7 +325,7 @@ __global__ __launch_bounds__(GeoS::THREADS) void mfma_f32_split_kernel(const cha
   // "+=" reads C in batches of 8 rows (16 registers): the kernel has ~25 spare registers in the main loop, so the 64
   // row-pairs of a lane cannot all be in flight; 8 dependent round trips per write-back.  (No-return float atomics
   // need no registers at all but run at ~0.8 TB/s chip-wide in the L2 -- measured 80 us per round of tiles.)
-  const unsigned row_w = tile_r * G::BM + wm * 128, col_w = tile_c * G::BN + wn * 64, col = col_w + 2 * lo;
+  const unsigned row_w = tile_r * G::BM + wm * (TM * 32), col_w = tile_c * G::BN + wn * 64, col = col_w + 2 * lo;
   char *const c_wave = (char *)uniform((const char *)(C + (size_t)row_w * M + col_w));
   const bool pairs = (M & 1u) == 0 && ((size_t)C & 7u) == 0;
   auto writeback = [&](bool accumulate, auto finalc) {
@@ -403,13 +418,12 @@ __global__ __launch_bounds__(GeoS::THREADS) void mfma_f32_split_kernel(const cha
   writeback(flushed, std::true_type{});
 }
 
-template <int VAR, int TERMS>
+template <int VAR, int TERMS, class G = GeoS>
 int launch_gemm(hipStream_t s, const char *ap, const char *bp, const Problem &p, unsigned slabs) {
-  using G = GeoS;
   static unsigned long long configured = 0;
   const unsigned tiles_n = (p.n + G::BM - 1) / G::BM, tiles_m = (p.m + G::BN - 1) / G::BN;
-  if (int e = ensure_dynamic_lds((const void *)mfma_f32_split_kernel<VAR, TERMS>, G::LDS_BYTES, configured)) return e;
-  hipLaunchKernelGGL((mfma_f32_split_kernel<VAR, TERMS>), dim3(tiles_n * tiles_m), dim3(G::THREADS), G::LDS_BYTES, s, ap,
+  if (int e = ensure_dynamic_lds((const void *)mfma_f32_split_kernel<VAR, TERMS, G>, G::LDS_BYTES, configured)) return e;
+  hipLaunchKernelGGL((mfma_f32_split_kernel<VAR, TERMS, G>), dim3(tiles_n * tiles_m), dim3(G::THREADS), G::LDS_BYTES, s, ap,
                      bp, (float *)p.c, p.n, p.m, slabs, tiles_n, tiles_m, band_rows());
   return (int)hipGetLastError();
 }
@@ -418,21 +432,31 @@ int launch_gemm(hipStream_t s, const char *ap, const char *bp, const Problem &p,
 
 bool mfma_f32_split_serves(const Problem &p) { return p.n > 0 && p.m > 0 && p.k > 0; }
 
+// 256 x 256 (ping-pong, one workgroup per CU) or 128 x 128 (two workgroups per CU) for problems whose 256-tiles
+// would leave compute units idle; same estimator as the other families (mm_common.h).  variant bit 8 (256) pins 256,
+// bit 9 (512) pins 128.
+int mfma_f32_split_tile(const Problem &p, int variant) {
+  if (variant > 0 && (variant & 256)) return 256;
+  if (variant > 0 && (variant & 512)) return 128;
+  static const TileCandidate cands[] = {{256, 256, 256, 1, 1.0}, {128, 128, 128, 2, 0.85}};
+  return pick_tile(cands, 2, p.n, p.m);
+}
+
 size_t mfma_f32_split_workspace_bytes(const Problem &p) {
   const size_t slabs = (p.k + 15) / 16;
-  return ((size_t)((p.n + 255) / 256) + (size_t)((p.m + 255) / 256)) * slabs * GeoS::SLAB_BYTES;
+  return ((size_t)((p.n + 255) / 256) + (size_t)((p.m + 255) / 256)) * slabs * Packed::SLAB_BYTES;
 }
 
 // variant (split_variant knob): -1 / 0 = default (6 products, ping-pong schedule, flush every 8256 k); otherwise a bit
 // mask: 1 first schedule of the round (one barrier per stage, fragment reads ahead of each MFMA group, s_setprio around
 // the group), 2 three products (planes 1 and 2 only), 4 no flush, 8 plain hipMalloc/hipFree workspace (diagnosis),
 // 16 no DMA in the main loop, 32 L2-resident sources (these two: ablations on the one-barrier schedule, see the kernel),
-// 64 flush every 4128 k, 128 one barrier per stage with the fragment reads interleaved between the MFMAs
+// 64 flush every 4128 k, 128 one barrier per stage with the fragment reads interleaved between the MFMAs,
+// 256 / 512 pin the 256 x 256 / 128 x 128 tile (default: by shape, mfma_f32_split_tile)
 int launch_mfma_f32_split(hipStream_t s, const Problem &p, int variant) {
-  using G = GeoS;
   const unsigned slabs = (p.k + 15) / 16;
   const unsigned blocks_a = (p.n + 255) / 256, blocks_b = (p.m + 255) / 256;
-  const size_t a_bytes = (size_t)blocks_a * slabs * G::SLAB_BYTES, b_bytes = (size_t)blocks_b * slabs * G::SLAB_BYTES;
+  const size_t a_bytes = (size_t)blocks_a * slabs * Packed::SLAB_BYTES, b_bytes = (size_t)blocks_b * slabs * Packed::SLAB_BYTES;
   // keep freed workspace in the device's pool between launches (the default threshold of 0 hands it back
   // to the driver at the next synchronisation, and the next launch pays a multi-GiB allocation again)
   static unsigned long long pool_configured = 0;
@@ -471,6 +495,7 @@ int launch_mfma_f32_split(hipStream_t s, const Problem &p, int variant) {
     else if (v & 2) rc = launch_gemm<64, 3>(s, ws, bp, p, slabs);
     else if (v & 4) rc = launch_gemm<64 | 2, 6>(s, ws, bp, p, slabs);
     else if (v & 64) rc = launch_gemm<64 | 32, 6>(s, ws, bp, p, slabs);
+    else if (mfma_f32_split_tile(p, v) == 128) rc = launch_gemm<16, 6, GeoS128>(s, ws, bp, p, slabs);
     else rc = launch_gemm<64, 6>(s, ws, bp, p, slabs);
   }
   hipError_t f;

@@ -111,6 +111,25 @@ def test_split_schedules_are_bit_identical(shape):
         assert np.array_equal(c, ref), variant
 
 
+@pytest.mark.parametrize("shape", [(513, 528, 528), (1024, 1024, 1024), (300, 8300, 272), (3, 5, 7), (2048, 4200, 1920)],
+                         ids=lambda s: "x".join(map(str, s)))
+def test_split_both_tiles_are_bit_identical(shape):
+    """The 128 x 128 tile (picked for problems that would leave compute units idle) runs the same per-accumulator MFMA
+    sequence as the 256 x 256 one: pinning either (variants 512 / 256) gives the same bits."""
+    n, k, m = shape
+    a, b = _oracle.fill("float", n, k, m)
+    g.set_tuning("split_variant", 256)
+    big, _ = g.matmul_capi(a, b, path=g.PATH_SPLIT)
+    g.set_tuning("split_variant", 512)
+    small, _ = g.matmul_capi(a, b, path=g.PATH_SPLIT)
+    assert np.array_equal(big, small)
+    info = g.kernel_info(g.make_config("float", path=g.PATH_SPLIT), n, k, m)
+    assert (info.tile_n, info.wavefronts) == (128, 4)
+    g.set_tuning("split_variant", -1)
+    auto, _ = g.matmul_capi(a, b, path=g.PATH_SPLIT)
+    assert np.array_equal(auto, big)
+
+
 def test_split_three_product_variant_is_the_coarser_class():
     """split_variant 2 keeps a1b1 + a1b2 + a2b1 only: passes 1e-5 on the reference's inputs, but not the 2^-21 bound
     machinery above by construction -- it must stay a knob, and it must be measurably coarser than the default."""
