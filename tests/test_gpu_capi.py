@@ -107,8 +107,11 @@ def test_concurrent_launches_from_two_threads_on_two_streams():
             ("float", ("Multiply", "Add"), (1024, 1024, 1024)), ("float", ("Add", "Min"), (640, 256, 384)),
             ("uint8_t", ("Multiply", "Add"), (512, 512, 512)), ("float", ("Multiply", "Add"), (300, 64, 272)),
             ("double", ("Multiply", "Add"), (513, 528, 528)), ("half", ("Multiply", "Add"), (520, 528, 528)),
-            ("float", ("Multiply", "Add"), (2048, 512, 2048)), ("int", ("Multiply", "Add"), (257, 64, 96))]):
-        n, k, m = shape
+            ("float", ("Multiply", "Add"), (2048, 512, 2048)), ("int", ("Multiply", "Add"), (257, 64, 96)),
+            # MM_PATH_SPLIT: stream-ordered workspace from both threads at once, both tile sizes
+            ("float", ("Multiply", "Add"), (4096, 300, 4100, g.PATH_SPLIT)), ("float", ("Multiply", "Add"), (300, 520, 260, g.PATH_SPLIT))]):
+        path = shape[3] if len(shape) == 4 else g.PATH_AUTO
+        n, k, m = shape[:3]
         tdt = g.torch_dtype(dtype)
         if dtype in ("uint8_t", "int"):
             a = torch.randint(1, 10, (n, k), device=dev).to(tdt)
@@ -116,8 +119,8 @@ def test_concurrent_launches_from_two_threads_on_two_streams():
         else:
             a = (torch.rand((n, k), device=dev) * 9 + 1).to(tdt)
             b = (torch.rand((k, m), device=dev) * 9 + 1).to(tdt)
-        jobs.append((dtype, ops, a, b))
-    serial = [g.matmul(a, b, dtype, *ops) for (dtype, ops, a, b) in jobs]
+        jobs.append((dtype, ops, a, b, path))
+    serial = [g.matmul(a, b, dtype, *ops, path=path) for (dtype, ops, a, b, path) in jobs]
     torch.cuda.synchronize()
     results = {}
     errors = []
@@ -131,11 +134,11 @@ def test_concurrent_launches_from_two_threads_on_two_streams():
                     if tid:
                         order.reverse()
                     for j in order:
-                        dtype, ops, a, b = jobs[j]
-                        out = g.matmul(a, b, dtype, *ops)
+                        dtype, ops, a, b, path = jobs[j]
+                        out = g.matmul(a, b, dtype, *ops, path=path)
                         results[(tid, rep, j)] = out
                     # a blocking, timed C-ABI launch from this thread while the other one enqueues
-                    dtype, ops, a, b = jobs[3]
+                    dtype, ops, a, b, _ = jobs[3]
                     cfg = g.make_config(dtype, *ops)
                     t = ctypes.c_double(0)
                     c = torch.empty((a.shape[0], b.shape[1]), dtype=a.dtype, device=dev)
