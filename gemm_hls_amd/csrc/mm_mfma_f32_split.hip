@@ -337,6 +337,36 @@ __global__ __launch_bounds__(G::THREADS) void mfma_f32_split_kernel(const char *
                                   // live across the main loop and spill)
     const unsigned lane_off = (4 * hi * Mv + 2 * lo) * 4u;
     const unsigned rows_left = N > row_w ? N - row_w : 0u;  // the lower wavefront row of a ragged tile may own no row at all
+    // Interior wavefront blocks (every row and column in range, 8-byte accesses possible): straight-line code, no
+    // per-lane predicate -- the predicated form below costs a branch and a full s_waitcnt per element, which
+    // serialises the 64 loads of a read-modify-write into 64 round trips.
+    const bool interior = pairs && row_w + TM * 32 <= N && col_w + 64 <= M;  // wavefront-uniform
+    if (interior) {
+      typedef __attribute__((address_space(1))) f32x2 *gpair_t;
+#pragma unroll
+      for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+        for (int half = 0; half < 16 / BATCH; ++half) {
+          f32x2 old[BATCH];
+          if (accumulate) {
+#pragma unroll
+            for (int j = 0; j < BATCH; ++j) {
+              const int rr = half * BATCH + j, lrow = mi * 32 + (rr & 3) + 8 * (rr >> 2);
+              old[j] = *(gpair_t)(c_wave + (lane_off + (unsigned)lrow * Mv * 4u));
+            }
+          } else {
+#pragma unroll
+            for (int j = 0; j < BATCH; ++j) old[j] = f32x2{0.0f, 0.0f};
+          }
+#pragma unroll
+          for (int j = 0; j < BATCH; ++j) {
+            const int rr = half * BATCH + j, lrow = mi * 32 + (rr & 3) + 8 * (rr >> 2);
+            *(gpair_t)(c_wave + (lane_off + (unsigned)lrow * Mv * 4u)) = f32x2{acc[mi][0][rr], acc[mi][1][rr]} + old[j];
+          }
+          if (!FINAL) __builtin_amdgcn_sched_barrier(0);
+        }
+      return;
+    }
 #pragma unroll
     for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
