@@ -26,8 +26,9 @@ BASELINE_CONFIGS = [  # BASELINE.json configs that fit one GPU
     ("half", "Multiply", "Add", 32768, 32768, 32768),
     ("double", "Multiply", "Add", 16384, 16384, 16384),
     ("float", "Add", "Min", 8192, 8192, 8192),
+    ("float", "Multiply", "Add", 16384, 16384, 16384, {"MM_PATH": "split"}),  # the opt-in fp32 path on the bf16 matrix cores
 ]
-QUICK_CONFIGS = [(t, m, r, 2048, 2048, 2048) for (t, m, r, *_rest) in BASELINE_CONFIGS]
+QUICK_CONFIGS = [(t, m, r, 2048, 2048, 2048, *rest) for (t, m, r, _n, _k, _m, *rest) in BASELINE_CONFIGS]
 
 
 def main():
@@ -42,14 +43,15 @@ def main():
         w = csv.writer(f)
         w.writerow(["data_type", "map_op", "reduce_op", "size_n", "size_k", "size_m", "kernel", "time", "performance",
                     "power", "power_efficiency"])
-        for (dt, mp, rd, n, k, m) in configs:
+        for (dt, mp, rd, n, k, m, *rest) in configs:
+            env = dict(os.environ, **(rest[0] if rest else {}))
             exe = os.path.join(ROOT, "bin", f"RunHardware_{dt}_{mp}_{rd}_power.exe")
             done = timeouts = 0
             while done < args.repetitions:
                 print(f"Running {dt} {mp}/{rd} {n}x{k}x{m}, iteration {done + 1} / {args.repetitions}...", flush=True)
                 try:
                     r = subprocess.run([exe, str(n), str(k), str(m), "hw", "off"], capture_output=True, text=True,
-                                       timeout=args.timeout)
+                                       timeout=args.timeout, env=env)
                 except subprocess.TimeoutExpired:
                     timeouts += 1
                     if timeouts > 10:
