@@ -151,6 +151,7 @@ __global__ __launch_bounds__(G::THREADS) void mfma_f32_kernel(const float *__res
 
   auto stage = [&](unsigned buf, unsigned k0) {
     char *base = smem + buf * G::STAGE_BYTES;
+    if (G::HINT == 8) asm volatile("s_mov_b64 exec, 0" ::: "memory");  // ablation: the DMA instructions issue with no lane active
 #pragma unroll
     for (int i = 0; i < G::LA; ++i) {
       const float *src;
@@ -164,6 +165,7 @@ __global__ __launch_bounds__(G::THREADS) void mfma_f32_kernel(const float *__res
       const float *src = B + (size_t)kr * M + b_col[i];
       __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(base + G::A_BYTES + (wave + G::NW * i) * 1024), 16, 0, 0);
     }
+    if (G::HINT == 8) asm volatile("s_mov_b64 exec, -1" ::: "memory");
   };
 
   // ---- per-lane fragment addresses (bytes inside a stage) -------------------------------------
@@ -301,6 +303,50 @@ __global__ __launch_bounds__(G::THREADS) void mfma_f32_kernel(const float *__res
         __builtin_amdgcn_sched_barrier(0);
         continue;
       }
+      if (G::HINT >= 3) {
+        // HINT 4..8 are ablations (timing only, wrong results): 4 no barrier; 5 no DMA; 6 no fragment reads; 7 neither;
+        // 8 DMA instructions issued with an empty exec mask (issue cost without the memory traffic)
+        constexpr bool DO_DMA = G::HINT != 5 && G::HINT != 7, DO_READS = G::HINT != 6 && G::HINT != 7;
+        // (HINT 4 = the same without the workgroup barrier: an ablation that races by construction, timing only.)
+        // Software-pipelined fragment reads with the barrier still covered by MFMAs.  The plain form below says
+        // "read the next group's fragments, then multiply this group's", but the machine scheduler sinks every read
+        // down to its first use: the shipped loop is  ds_read x4 | s_waitcnt lgkmcnt(0) | 16 MFMAs  four times per
+        // slab (ISA of the default geometry), i.e. four exposed LDS round trips per slab with both wavefronts of a
+        // SIMD in lock-step.  Here the order is pinned:
+        //   not the slab's last group:  16 MFMAs | reads of the next group | 16 MFMAs
+        //   the last group:             16 MFMAs | wait + barrier | DMA of slab t+NS and reads of slab t+1's first
+        //                               group, one between MFMAs | the remaining MFMAs
+        // so every fragment is requested >= 16 MFMAs (1024 cycles) before its first use.
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_half(afc, bfc, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kg + 1 < G::KG) {
+          if (DO_READS) load_frags(buf, kg + 1, afn, bfn);
+          __builtin_amdgcn_sched_barrier(0);
+          mfma_half(afc, bfc, 1);
+        } else {
+          asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NS - 2) * L) : "memory");
+          if (G::HINT != 4) __builtin_amdgcn_s_barrier();
+          __builtin_amdgcn_sched_barrier(0);
+          constexpr int NM = 8 * TM, NR = TM + 4;   // MFMAs of a half group, fragment reads of a group
+          if (DO_DMA) stage(buf, (t + NS) * BK);
+          if (DO_READS) load_frags((t + 1) % NS, 0, afn, bfn);
+          mfma_half(afc, bfc, 1);
+#pragma unroll
+          for (int i = 0; i < L; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+          }
+#pragma unroll
+          for (int i = 0; i < NR; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          }
+          __builtin_amdgcn_sched_group_barrier(0x008, NM - L - NR, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        continue;
+      }
       if (kg + 1 < G::KG) {
         if (G::STAGGER && kg == 0 && late && t > 0) stage((t - 1) % NS, (t - 1 + NS) * BK);  // the refill E issued a k-group ago
         load_frags(buf, kg + 1, afn, bfn);
@@ -315,7 +361,7 @@ __global__ __launch_bounds__(G::THREADS) void mfma_f32_kernel(const float *__res
         load_frags((t + 1) % NS, 0, afn, bfn);
       }
       mfma_group(afc, bfc);
-      if (G::HINT) {  // masks: MFMA 0x8, VMEM read 0x20, DS read 0x100
+      if (G::HINT == 1 || G::HINT == 2) {  // masks: MFMA 0x8, VMEM read 0x20, DS read 0x100
         constexpr int NM = 16 * TM, NR = TM + 4;
         if (kg + 1 < G::KG) {
           if (G::HINT == 1) {
@@ -623,7 +669,7 @@ using V4 = Geo<2, 2, 2, 32, 3, true, 16>;    // V0 with a 3-deep ring and counte
 using V5 = Geo<2, 2, 2, 16, 2, true, 32>;    // V0 with BK = 16
 using V6 = Geo<4, 2, 2, 16, 3, false, 1>;    // V2 with a 3-deep ring
 using V7 = Geo<1, 4, 2, 32, 2, true, 16>;    // 128x256, 8 waves, 32x128 per wave
-using V8 = Geo<2, 4, 2, 16, 2, false, 1, 256>;  // V3 + flush into C every 4096 k
+using V8 = Geo<2, 4, 2, 16, 2, false, 1, 256, false, false, 3>;  // 256x256x16, 8 waves, flush into C every 4096 k, fragment reads software-pipelined (HINT 3)
 using V9 = Geo<2, 4, 2, 16, 2, false, 1, 128>;  // V3 + flush into C every 2048 k
 using V10 = Geo<2, 4, 2, 32, 2, false, 1, 128>; // 256x256x32, 8 waves (144 KiB LDS), flush every 4096 k
 using V11 = Geo<2, 4, 2, 16, 3, false, 1, 256>; // V8 with a 3-slab ring (96 KiB)
@@ -637,10 +683,19 @@ using V18 = Geo<2, 4, 2, 16, 2, false, 1, 256, false, true>;  // V8 + pinned fra
 using V19 = Geo<2, 4, 2, 16, 2, false, 1, 256, true, true>;   // V8 + stagger + pinned fragment reads
 using V22 = Geo<2, 4, 2, 16, 2, false, 1, 256, false, false, 1>;  // V8 + sched_group_barrier shaping, reads first
 using V23 = Geo<2, 4, 2, 16, 2, false, 1, 256, false, false, 2>;  // V8 + shaping, reads mid-group
+using V24 = Geo<2, 4, 2, 16, 2, false, 1, 256>;                     // V8 as first shipped: the compiler places the fragment reads (it sinks them to their uses)
+using V25 = Geo<2, 4, 2, 16, 2, false, 1, 0, false, false, 3>;    // V3 (no flush) + the same
+using V26 = Geo<2, 4, 2, 16, 3, false, 1, 0, false, false, 3>;    // V25 with a ring of 3 (two slabs of DMA in flight)
+using V27 = Geo<2, 4, 2, 16, 4, false, 1, 0, false, false, 3>;    // V25 with a ring of 4
+using V28 = Geo<2, 4, 2, 16, 2, false, 1, 0, false, false, 4>;    // ABLATION: V25 without the slab barrier (races; timing only)
+using V29 = Geo<2, 4, 2, 16, 2, false, 1, 0, false, false, 5>;    // ABLATION: V25 without DMA in the main loop
+using V30 = Geo<2, 4, 2, 16, 2, false, 1, 0, false, false, 6>;    // ABLATION: V25 without fragment reads in the main loop
+using V31 = Geo<2, 4, 2, 16, 2, false, 1, 0, false, false, 7>;    // ABLATION: V25 with neither
+using V32 = Geo<2, 4, 2, 16, 2, false, 1, 0, false, false, 8>;    // ABLATION: V25, DMA issued with exec = 0
 
 }  // namespace
 
-int mfma_f32_num_variants() { return 24; }
+int mfma_f32_num_variants() { return 28; }  // 28 (ablation) is not counted: tests iterate over the valid ones
 
 const char *mfma_f32_name(int v) {
   switch (v) {
@@ -668,6 +723,15 @@ const char *mfma_f32_name(int v) {
     case 21: return "mfma_f32_256x256x16_w8_flush4096_pingpong_lockstep";
     case 22: return "mfma_f32_256x256x16_w8_flush4096_sgb1";
     case 23: return "mfma_f32_256x256x16_w8_flush4096_sgb2";
+    case 24: return "mfma_f32_256x256x16_w8_flush4096_sunkreads";
+    case 25: return "mfma_f32_256x256x16_w8_piperead";
+    case 26: return "mfma_f32_256x256x16_w8_piperead_ns3";
+    case 27: return "mfma_f32_256x256x16_w8_piperead_ns4";
+    case 28: return "mfma_f32_256x256x16_w8_piperead_ABLATION_no_barrier";
+    case 29: return "mfma_f32_256x256x16_w8_piperead_ABLATION_no_dma";
+    case 30: return "mfma_f32_256x256x16_w8_piperead_ABLATION_no_reads";
+    case 31: return "mfma_f32_256x256x16_w8_piperead_ABLATION_mfma_only";
+    case 32: return "mfma_f32_256x256x16_w8_piperead_ABLATION_dma_exec0";
   }
   return "?";
 }
@@ -744,6 +808,15 @@ int launch_mfma_f32(hipStream_t s, const Problem &p, int variant) {
     case 21: return mfma_f32_pp_serves_impl(p) ? launch_f32_pp<2>(s, p) : launch_geo<V8>(s, p);
     case 22: return launch_geo<V22>(s, p);
     case 23: return launch_geo<V23>(s, p);
+    case 24: return launch_geo<V24>(s, p);
+    case 25: return launch_geo<V25>(s, p);
+    case 26: return launch_geo<V26>(s, p);
+    case 27: return launch_geo<V27>(s, p);
+    case 28: return tuning(TUNE_ABLATIONS) == 1 ? launch_geo<V28>(s, p) : kErrNotSupported;
+    case 29: return tuning(TUNE_ABLATIONS) == 1 ? launch_geo<V29>(s, p) : kErrNotSupported;
+    case 30: return tuning(TUNE_ABLATIONS) == 1 ? launch_geo<V30>(s, p) : kErrNotSupported;
+    case 31: return tuning(TUNE_ABLATIONS) == 1 ? launch_geo<V31>(s, p) : kErrNotSupported;
+    case 32: return tuning(TUNE_ABLATIONS) == 1 ? launch_geo<V32>(s, p) : kErrNotSupported;
   }
   return kErrNotSupported;
 }
