@@ -89,6 +89,9 @@ struct Geo {
   static constexpr int A_BYTES = BM * BK * 4, B_BYTES = BK * BN * 4;
   static constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
   static constexpr int LDS_BYTES = NS * STAGE_BYTES;
+  // 4-wavefront geometries whose LDS and accumulators fit twice on a CU are compiled for 2 wavefronts per SIMD
+  // (<= 256 VGPRs): two INDEPENDENT workgroups then share every SIMD, each with its own barriers
+  static constexpr int MIN_WAVES = (NW == 4 && 2 * LDS_BYTES <= 160 * 1024 && (TWO_LEVEL_ ? 2 : 1) * TM * TN * 16 <= 128) ? 2 : 1;
   static constexpr int NA = A_BYTES / 1024, NB = B_BYTES / 1024;  // wave-level DMA instructions
   static constexpr int LA = NA / NW, LB = NB / NW;                // ... per wavefront
   static constexpr int KG = BK / 8;                               // 8-deep k-groups per slab
@@ -99,7 +102,7 @@ struct Geo {
 };
 
 template <typename G, bool AT>
-__global__ __launch_bounds__(G::THREADS) void mfma_f32_kernel(const float *__restrict__ A,
+__global__ __launch_bounds__(G::THREADS, G::MIN_WAVES) void mfma_f32_kernel(const float *__restrict__ A,
                                                               const float *__restrict__ B,
                                                               float *__restrict__ C, unsigned N,
                                                               unsigned K, unsigned M,
@@ -692,6 +695,8 @@ using V29 = Geo<2, 4, 2, 16, 2, false, 1, 0, false, false, 5>;    // ABLATION: V
 using V30 = Geo<2, 4, 2, 16, 2, false, 1, 0, false, false, 6>;    // ABLATION: V25 without fragment reads in the main loop
 using V31 = Geo<2, 4, 2, 16, 2, false, 1, 0, false, false, 7>;    // ABLATION: V25 with neither
 using V32 = Geo<2, 4, 2, 16, 2, false, 1, 0, false, false, 8>;    // ABLATION: V25, DMA issued with exec = 0
+using V33 = Geo<2, 2, 2, 16, 2, false, 1, 256, false, false, 3>;  // V15 (128x256x16, 4 waves, 2 workgroups per CU) + pipelined reads
+using V34 = Geo<2, 2, 2, 16, 3, false, 1, 256, false, false, 3>;  // the same with a ring of 3 (72 KiB LDS)
 
 }  // namespace
 
@@ -732,6 +737,8 @@ const char *mfma_f32_name(int v) {
     case 30: return "mfma_f32_256x256x16_w8_piperead_ABLATION_no_reads";
     case 31: return "mfma_f32_256x256x16_w8_piperead_ABLATION_mfma_only";
     case 32: return "mfma_f32_256x256x16_w8_piperead_ABLATION_dma_exec0";
+    case 33: return "mfma_f32_128x256x16_w4_flush4096_2percu_piperead";
+    case 34: return "mfma_f32_128x256x16_w4_flush4096_2percu_piperead_ns3";
   }
   return "?";
 }
@@ -760,6 +767,8 @@ void mfma_f32_geometry(int v, unsigned *bm, unsigned *bn, unsigned *bk, unsigned
     case 17: return geo_of<V17>(bm, bn, bk, waves);
     case 18: return geo_of<V18>(bm, bn, bk, waves);
     case 19: return geo_of<V19>(bm, bn, bk, waves);
+    case 33: return geo_of<V33>(bm, bn, bk, waves);
+    case 34: return geo_of<V34>(bm, bn, bk, waves);
     default: return geo_of<V8>(bm, bn, bk, waves);
   }
 }
@@ -770,7 +779,9 @@ void mfma_f32_geometry(int v, unsigned *bm, unsigned *bn, unsigned *bk, unsigned
 // the candidate with the smallest estimated time = (workgroups the busiest CU runs) x tile area /
 // relative efficiency.
 int mfma_f32_auto_variant(const Problem &p) {
-  static const TileCandidate cands[] = {{8, 256, 256, 1, 1.00}, {13, 128, 256, 1, 0.95}, {14, 128, 128, 2, 0.94}};
+  // relative efficiencies measured at 8192^3 / 16384^3 (profiles/r02z_f32_two_workgroups_per_cu.log): the 128x256 tile as
+  // two independent 4-wavefront workgroups per CU (33) reaches 0.98 of the 256x256 kernel, the 128x128 one (14) 0.945
+  static const TileCandidate cands[] = {{8, 256, 256, 1, 1.00}, {33, 128, 256, 2, 0.98}, {14, 128, 128, 2, 0.945}};
   return pick_tile(cands, 3, p.n, p.m);
 }
 
@@ -817,6 +828,8 @@ int launch_mfma_f32(hipStream_t s, const Problem &p, int variant) {
     case 30: return tuning(TUNE_ABLATIONS) == 1 ? launch_geo<V30>(s, p) : kErrNotSupported;
     case 31: return tuning(TUNE_ABLATIONS) == 1 ? launch_geo<V31>(s, p) : kErrNotSupported;
     case 32: return tuning(TUNE_ABLATIONS) == 1 ? launch_geo<V32>(s, p) : kErrNotSupported;
+    case 33: return launch_geo<V33>(s, p);
+    case 34: return launch_geo<V34>(s, p);
   }
   return kErrNotSupported;
 }

@@ -28,9 +28,10 @@ using f64x4 = __attribute__((ext_vector_type(4))) double;
 typedef const __attribute__((address_space(1))) void *gptr_t;
 typedef __attribute__((address_space(3))) void *lptr_t;
 
-template <int WM_, int WN_, int NS_>
+template <int WM_, int WN_, int NS_, bool PIPE_ = true>
 struct GeoD {
   static constexpr int WM = WM_, WN = WN_, NS = NS_;
+  static constexpr bool PIPE = PIPE_;  // pinned, software-pipelined fragment reads (see the main loop)
   static constexpr int TM = 4, TP = 2;               // 4 row tiles x (2 pairs of column tiles) of 16
   static constexpr int NW = WM * WN, THREADS = NW * 64;
   static constexpr int BM = WM * 64, BN = WN * 64, BK = 16;
@@ -46,7 +47,9 @@ struct GeoD {
 };
 
 template <typename G, bool AT>
-__global__ __launch_bounds__(G::THREADS) void mfma_f64_kernel(const double *__restrict__ A,
+__global__ __launch_bounds__(G::THREADS, 2) void mfma_f64_kernel(  // 2 wavefronts per SIMD: <= 256 VGPRs, so that the
+                                                                   // 4-wavefront geometry really fits twice on a CU
+    const double *__restrict__ A,
                                                               const double *__restrict__ B,
                                                               double *__restrict__ C, unsigned N, unsigned K,
                                                               unsigned M, unsigned tiles_n, unsigned tiles_m, unsigned kBand) {
@@ -161,10 +164,58 @@ __global__ __launch_bounds__(G::THREADS) void mfma_f64_kernel(const double *__re
   f64x2 af0[TM], bf0[2][TP], af1[TM], bf1[2][TP];
   load_frags(0, 0, af0, bf0);
 
+  // the two p-halves of a k-group, in mfma_group's order
+  auto mfma_half = [&](const f64x2 (&af)[TM], const f64x2 (&bf)[2][TP], int p) {
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+      for (int pr = 0; pr < TP; ++pr) {
+        acc[mi][pr][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[mi][p], bf[p][pr][0], acc[mi][pr][0], 0, 0, 0);
+        acc[mi][pr][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[mi][p], bf[p][pr][1], acc[mi][pr][1], 0, 0, 0);
+      }
+  };
+
   // one full slab with a successor; KG == 2: group 0 from set 0, group 1 from set 1 (see f32 kernel)
   const unsigned steady = num_tiles - 1;
   for (unsigned t = 0; t < steady; ++t) {
     const unsigned buf = t % NS;
+    if (G::PIPE) {
+      // Pinned order (round 2).  Written plainly ("read the next group, multiply this one, barrier, refill, ...") the
+      // machine scheduler moved BOTH groups' MFMAs behind the barrier: per slab the matrix core then waited for 8
+      // fragment reads, the barrier and 6 DMA issues in a row (MfmaUtil 92 %).  Here every fragment is requested 16
+      // MFMAs before its first use and the barrier sits between two MFMA halves:
+      //   16 MFMAs | reads of group 1 | 16 MFMAs | 16 MFMAs | wait + barrier | (MFMA, DMA piece) x L,
+      //   (MFMA, read of slab t+1's group 0) x 8, remaining MFMAs
+      constexpr int NM = 4 * TM * TP / 2 * 2 / 2, NR = TM + 2 * TP;  // MFMAs per half group (16), reads per group (8)
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_half(af0, bf0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      load_frags(buf, 1, af1, bf1);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_half(af0, bf0, 1);
+      mfma_half(af1, bf1, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NS - 2) * L) : "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      stage(buf, (t + NS) * BK);
+      load_frags((t + 1) % NS, 0, af0, bf0);
+      mfma_half(af1, bf1, 1);
+      static_assert(L + NR <= NM, "post-barrier half group too short for the interleave");
+#pragma unroll
+      for (int i = 0; i < L; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < NR; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, NM - L - NR, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      continue;
+    }
     load_frags(buf, 1, af1, bf1);
     mfma_group(af0, bf0);
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NS - 2) * L) : "memory");
@@ -206,6 +257,8 @@ __global__ __launch_bounds__(G::THREADS) void mfma_f64_kernel(const double *__re
 
 using D0 = GeoD<4, 2, 2>;  // 256 x 128 tile, 8 wavefronts (2 per SIMD), 96 KiB LDS
 using D1 = GeoD<2, 2, 2>;  // 128 x 128 tile, 4 wavefronts, 64 KiB LDS: two workgroups per CU (small / mid-size shapes)
+using D0R1 = GeoD<4, 2, 2, false>;  // the same tiles with the compiler-placed schedule they first shipped with (f64_variant 2 / 3)
+using D1R1 = GeoD<2, 2, 2, false>;
 
 }  // namespace
 
@@ -232,13 +285,16 @@ static int launch_d(hipStream_t s, const Problem &p) {
 
 int mfma_f64_tile(const Problem &p) {  // 0: 256x128, 1: 128x128
   const int v = tuning(TUNE_F64_VARIANT);
-  if (v >= 0) return v;
-  static const TileCandidate cands[] = {{0, 256, 128, 1, 1.00}, {1, 128, 128, 2, 0.74}};
+  if (v >= 0) return v & 1;
+  // measured (profiles/r02z_f64_pinned_schedule.log): with two workgroups per CU the small tile sustains the same
+  // 74.6 TF as the large one at 16384^3; the large one is kept on ties (fewer, larger DMA streams per CU)
+  static const TileCandidate cands[] = {{0, 256, 128, 1, 1.00}, {1, 128, 128, 2, 0.995}};
   return pick_tile(cands, 2, p.n, p.m);
 }
 
 int launch_mfma_f64(hipStream_t s, const Problem &p) {
   if (!mfma_f64_serves(p)) return kErrNotSupported;
+  if (tuning(TUNE_F64_VARIANT) >= 2) return mfma_f64_tile(p) == 1 ? launch_d<D1R1>(s, p) : launch_d<D0R1>(s, p);
   return mfma_f64_tile(p) == 1 ? launch_d<D1>(s, p) : launch_d<D0>(s, p);
 }
 

@@ -47,7 +47,7 @@ def test_f32_mfma_default_vs_blas_and_exact(shape):
     assert np.max(np.abs(c - exact) / exact) < F32_TOL
 
 
-@pytest.mark.parametrize("variant", range(28))
+@pytest.mark.parametrize("variant", list(range(28)) + [33, 34])
 @pytest.mark.parametrize("shape", [(513, 528, 528), (300, 64, 272), (256, 8, 4), (37, 32, 48), (300, 8208, 272)],
                          ids=lambda s: "x".join(map(str, s)))
 def test_f32_mfma_every_variant(variant, shape):
@@ -104,6 +104,27 @@ def test_f32_mfma_transpose_detecting_inputs():
     b = (np.arange(k * m, dtype=np.float32).reshape(k, m) % 1021) + 1.0
     c, _ = g.matmul_capi(a, b)
     assert np.array_equal(c, (a.astype(np.float64) @ b.astype(np.float64)).astype(np.float32))
+
+
+@pytest.mark.parametrize("shape", [(513, 528, 528), (300, 1040, 272), (130, 80, 260), (1024, 1024, 1024)],
+                         ids=lambda s: "x".join(map(str, s)))
+def test_f64_schedules_and_tiles_are_bit_identical(shape):
+    """f64_variant 0 / 1 = 256x128 / 128x128 tile with the pinned, software-pipelined schedule; 2 / 3 = the same tiles
+    with the compiler-placed schedule of round 1.  Same per-accumulator fma chain in all four, and through the K x N
+    layout of A."""
+    n, k, m = shape
+    a, b = _oracle.fill("double", n, k, m)
+    out = []
+    for v in (0, 1, 2, 3):
+        g.set_tuning("f64_variant", v)
+        c, _ = g.matmul_capi(a, b, "double")
+        out.append(c)
+        if n % 2 == 0:
+            ct, _ = g.matmul_capi(np.ascontiguousarray(a.T), b, "double", transposed_a=True)
+            out.append(ct)
+    g.set_tuning("f64_variant", -1)
+    for c in out[1:]:
+        assert np.array_equal(c, out[0])
 
 
 @pytest.mark.parametrize("shape", [(513, 528, 528), (1, 16, 8), (37, 32, 48), (300, 64, 272), (129, 80, 264), (257, 1040, 520)],
