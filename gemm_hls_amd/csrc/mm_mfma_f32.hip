@@ -320,20 +320,27 @@ __global__ __launch_bounds__(G::THREADS, G::MIN_WAVES) void mfma_f32_kernel(cons
         //   the last group:             16 MFMAs | wait + barrier | DMA of slab t+NS and reads of slab t+1's first
         //                               group, one between MFMAs | the remaining MFMAs
         // so every fragment is requested >= 16 MFMAs (1024 cycles) before its first use.
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_half(afc, bfc, 0);
+        constexpr int NM = 8 * TM, NR = TM + 4;   // MFMAs of a half group, fragment reads of a group
+        constexpr bool EARLY = L + NR > NM;       // narrow wavefront tiles: the post-barrier interleave needs the whole group
+        static_assert(L + NR <= 2 * NM, "a k-group has too few MFMAs to spread the DMA pieces and reads over");
         __builtin_amdgcn_sched_barrier(0);
         if (kg + 1 < G::KG) {
+          mfma_half(afc, bfc, 0);
+          __builtin_amdgcn_sched_barrier(0);
           if (DO_READS) load_frags(buf, kg + 1, afn, bfn);
           __builtin_amdgcn_sched_barrier(0);
           mfma_half(afc, bfc, 1);
         } else {
+          if (!EARLY) {
+            mfma_half(afc, bfc, 0);
+            __builtin_amdgcn_sched_barrier(0);
+          }
           asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NS - 2) * L) : "memory");
           if (G::HINT != 4) __builtin_amdgcn_s_barrier();
           __builtin_amdgcn_sched_barrier(0);
-          constexpr int NM = 8 * TM, NR = TM + 4;   // MFMAs of a half group, fragment reads of a group
           if (DO_DMA) stage(buf, (t + NS) * BK);
           if (DO_READS) load_frags((t + 1) % NS, 0, afn, bfn);
+          if (EARLY) mfma_half(afc, bfc, 0);
           mfma_half(afc, bfc, 1);
 #pragma unroll
           for (int i = 0; i < L; ++i) {
@@ -345,7 +352,7 @@ __global__ __launch_bounds__(G::THREADS, G::MIN_WAVES) void mfma_f32_kernel(cons
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
           }
-          __builtin_amdgcn_sched_group_barrier(0x008, NM - L - NR, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, (EARLY ? 2 : 1) * NM - L - NR, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
         continue;
@@ -697,6 +704,7 @@ using V31 = Geo<2, 4, 2, 16, 2, false, 1, 0, false, false, 7>;    // ABLATION: V
 using V32 = Geo<2, 4, 2, 16, 2, false, 1, 0, false, false, 8>;    // ABLATION: V25, DMA issued with exec = 0
 using V33 = Geo<2, 2, 2, 16, 2, false, 1, 256, false, false, 3>;  // V15 (128x256x16, 4 waves, 2 workgroups per CU) + pipelined reads
 using V34 = Geo<2, 2, 2, 16, 3, false, 1, 256, false, false, 3>;  // the same with a ring of 3 (72 KiB LDS)
+using V35 = Geo<1, 4, 1, 32, 2, false, 1, 128, false, false, 3>;  // V14 (128x128x32, 2 workgroups per CU) + pipelined reads
 
 }  // namespace
 
@@ -739,6 +747,7 @@ const char *mfma_f32_name(int v) {
     case 32: return "mfma_f32_256x256x16_w8_piperead_ABLATION_dma_exec0";
     case 33: return "mfma_f32_128x256x16_w4_flush4096_2percu_piperead";
     case 34: return "mfma_f32_128x256x16_w4_flush4096_2percu_piperead_ns3";
+    case 35: return "mfma_f32_128x128x32_w4_flush4096_piperead";
   }
   return "?";
 }
@@ -769,6 +778,7 @@ void mfma_f32_geometry(int v, unsigned *bm, unsigned *bn, unsigned *bk, unsigned
     case 19: return geo_of<V19>(bm, bn, bk, waves);
     case 33: return geo_of<V33>(bm, bn, bk, waves);
     case 34: return geo_of<V34>(bm, bn, bk, waves);
+    case 35: return geo_of<V35>(bm, bn, bk, waves);
     default: return geo_of<V8>(bm, bn, bk, waves);
   }
 }
@@ -779,10 +789,15 @@ void mfma_f32_geometry(int v, unsigned *bm, unsigned *bn, unsigned *bk, unsigned
 // the candidate with the smallest estimated time = (workgroups the busiest CU runs) x tile area /
 // relative efficiency.
 int mfma_f32_auto_variant(const Problem &p) {
-  // relative efficiencies measured at 8192^3 / 16384^3 (profiles/r02z_f32_two_workgroups_per_cu.log): the 128x256 tile as
-  // two independent 4-wavefront workgroups per CU (33) reaches 0.98 of the 256x256 kernel, the 128x128 one (14) 0.945
-  static const TileCandidate cands[] = {{8, 256, 256, 1, 1.00}, {33, 128, 256, 2, 0.98}, {14, 128, 128, 2, 0.945}};
-  return pick_tile(cands, 3, p.n, p.m);
+  // relative efficiencies measured at 8192^3 / 16384^3 (profiles/r02z_f32_two_workgroups_per_cu.log, r02z_f32_small_tile_
+  // pipelined.log): the 128x256 tile as two independent 4-wavefront workgroups per CU (33) reaches 0.98 of the 256x256
+  // kernel, the 128x128 one with pinned reads (35) 0.965
+  static const TileCandidate cands[] = {{8, 256, 256, 1, 1.00}, {33, 128, 256, 2, 0.98}, {35, 128, 128, 2, 0.965}};
+  const int pick = pick_tile(cands, 3, p.n, p.m);
+  // a launch that fits in ONE round of resident workgroups has no steady state to pipeline: the compiler-placed
+  // schedule (14) is 2 % ahead there (2048^3: 125.0 vs 122.1 TF)
+  const unsigned long long tiles = (unsigned long long)((p.n + 127) / 128) * ((p.m + 127) / 128);
+  return pick == 35 && tiles <= 512 ? 14 : pick;
 }
 
 bool mfma_f32_serves(const Problem &p) {
@@ -830,6 +845,7 @@ int launch_mfma_f32(hipStream_t s, const Problem &p, int variant) {
     case 32: return tuning(TUNE_ABLATIONS) == 1 ? launch_geo<V32>(s, p) : kErrNotSupported;
     case 33: return launch_geo<V33>(s, p);
     case 34: return launch_geo<V34>(s, p);
+    case 35: return launch_geo<V35>(s, p);
   }
   return kErrNotSupported;
 }
