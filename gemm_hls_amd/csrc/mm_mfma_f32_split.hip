@@ -7,7 +7,7 @@
 // ~2^-25 relative -- finer than the 2^-24 rounding of an fp32 multiply -- and the accumulation is
 // fp32, 16 k per instruction (v_mfma_f32_32x32x16_bf16) instead of the fp32 MFMA's 2.
 // Why: the fp32 MFMA (v_mfma_f32_32x32x2_f32) peaks at 157.3 TFLOP/s; six bf16 MFMAs per 16 k do the
-// same work in 6 x 32 cycles instead of 8 x 64 -- 2.67x at equal clock (DESIGN.md 3.4).
+// same work in 6 x 32 cycles instead of 8 x 64 -- 2.67x at equal clock (DESIGN.md 3.3).
 // This is MM_PATH_SPLIT: opt-in, same role as the reference's kernel (C = A x B, fp32 in, fp32 out,
 // include/MatrixMultiplication.h:155-171), tolerance-checked like every fp32 fast path.
 //
@@ -19,7 +19,7 @@
 //     (full cache lines, no swizzle arithmetic) and its fragment reads are lane-linear ds_read_b128
 //     (conflict-free by construction, no transpose reads).  Rows / columns / k beyond the matrix are
 //     written as zeros, so the GEMM kernel has no edge handling on loads and serves ANY N, K, M.
-//     Cost: reads 4 B, writes 6 B per element of A and B -- O(N^2), ~1.5 % of the launch at 16384^3.
+//     Cost: reads 4 B, writes 6 B per element of A and B at 4.5 TB/s -- O(N^2), 3.4 % of the launch at 16384^3.
 //  2. GEMM: 256 x 256 tile per workgroup, 8 wavefronts (2 x 4, 128 x 64 each = 4 x 2 MFMA tiles),
 //     ring of three 48 KiB stages (A slab + B slab) filled by global_load_lds_dwordx4 two stages
 //     ahead, counted vmcnt.  Per stage a wavefront issues 48 MFMAs (1536 cycles) against 18 fragment
@@ -135,11 +135,9 @@ __device__ __forceinline__ const char *uniform(const char *p) {
 // TERMS: 6 (default) or 3 (a1b2 + a2b1 + a1b1 only:
 // products to ~2^-16, the "three-pass" accuracy class; measurement knob, not dispatched by default).
 template <int VAR, int TERMS, class G = GeoS>
-__global__ __launch_bounds__(G::THREADS) void mfma_f32_split_kernel(const char *__restrict__ Ap,
-                                                                         const char *__restrict__ Bp,
-                                                                         float *__restrict__ C, unsigned N, unsigned M,
-                                                                         unsigned slabs, unsigned tiles_n,
-                                                                         unsigned tiles_m, unsigned kBand) {
+__global__ __launch_bounds__(G::THREADS, 2)  // 2 wavefronts per SIMD in both geometries
+void mfma_f32_split_kernel(const char *__restrict__ Ap, const char *__restrict__ Bp, float *__restrict__ C, unsigned N,
+                           unsigned M, unsigned slabs, unsigned tiles_n, unsigned tiles_m, unsigned kBand) {
   constexpr int TM = G::TM, TN = G::TN;
   constexpr int NP = TERMS == 6 ? 3 : 2;  // planes read
   extern __shared__ __attribute__((aligned(16))) char smem[];
