@@ -86,3 +86,31 @@ def test_fuzz_unaligned_shapes_take_the_predicated_path_and_stay_exact():
                 assert _oracle.compare("float", c, want, 1e-5)[0] == 0, (n, k, m)
             else:
                 assert np.array_equal(c, want), (dtype, ops, n, k, m)
+
+
+def test_fuzz_split_path_any_shape_mixed_sign():
+    """MM_PATH_SPLIT takes any N, K, M (the pack step pads): odd sizes straddling fragment (32), tile (128 / 256), slab
+    (16) and flush (8256 k) boundaries, mixed-sign operands, both layouts of A, both tiles -- normwise against fp64 and
+    bitwise between the two tile sizes."""
+    rng = np.random.default_rng(2024)
+    sizes = [1, 2, 31, 32, 33, 63, 65, 127, 129, 255, 256, 257, 300, 383, 511, 513, 700]
+    for i in range(40 * SCALE):
+        n, m = int(rng.choice(sizes)), int(rng.choice(sizes))
+        k = int(rng.choice([8256, 8257, 8272, 16511])) if i % 8 == 0 else int(rng.integers(1, 700))
+        if i % 8 == 0:
+            n, m = min(n, 257), min(m, 257)
+        a = rng.uniform(-3, 3, size=(n, k)).astype(np.float32)
+        b = rng.uniform(-3, 3, size=(k, m)).astype(np.float32)
+        exact = a.astype(np.float64) @ b.astype(np.float64)
+        den = np.abs(a).astype(np.float64) @ np.abs(b).astype(np.float64)
+        out = []
+        for variant in (256, 512):                       # pinned 256 x 256 / 128 x 128 tile
+            g.set_tuning("split_variant", variant)
+            c, _ = g.matmul_capi(a, b, path=g.PATH_SPLIT)
+            out.append(c)
+        g.set_tuning("split_variant", -1)
+        assert np.array_equal(out[0], out[1]), (n, k, m)
+        assert float(np.max(np.abs(out[0] - exact) / np.maximum(den, 1e-300))) < 2.0 ** -19, (n, k, m)
+        if i % 4 == 0:
+            ct, _ = g.matmul_capi(np.ascontiguousarray(a.T), b, path=g.PATH_SPLIT, transposed_a=True)
+            assert np.array_equal(ct, out[0]), (n, k, m)
