@@ -224,8 +224,50 @@ __global__ __launch_bounds__(G::THREADS, G::MIN_WAVES) void mfma_f32_kernel(cons
           acc[mi][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi][p], bf[p][t], acc[mi][t], 0, 0, 0);
   };
 
+  // Interior wavefront blocks (all rows and 128 columns in range): straight-line C (+)= values, BATCH rows in flight at
+  // a time.  The predicated forms below cost a branch and a full s_waitcnt per row, which turns the 32 loads of a
+  // read-modify-write into 32 dependent round trips.
+  typedef __attribute__((address_space(1))) f32x4 *gquad_t;
+  const bool interior_block = col0 + wn * 128 + 128 <= M && row0 + wm * TM * 32 + TM * 32 <= N;  // wavefront-uniform
+  auto rmw_interior = [&](bool accumulate, auto batchc, auto value) {
+    constexpr int BATCH = decltype(batchc)::value;
+    unsigned Mv = M;
+    asm volatile("" : "+s"(Mv));  // opaque: the row offsets must not be hoisted out of the chunk loop (they would stay
+                                  // live across the main loop and cost it registers)
+    char *base = (char *)(C + (size_t)(row0 + wm * TM * 32) * Mv + col0 + wn * 128);
+    const unsigned lane_off = ((AT ? TM * 4 * hi : 4 * hi) * Mv + 4 * lo) * 4u;
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+      for (int r0 = 0; r0 < 16; r0 += BATCH) {
+        f32x4 old[BATCH];
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j) {
+          const int r = r0 + j, ri = (r & 3) + 8 * (r >> 2), lrow = AT ? TM * ri + mi : mi * 32 + ri;
+          old[j] = accumulate ? *(gquad_t)(base + (lane_off + (unsigned)lrow * Mv * 4u)) : (f32x4)0.0f;
+        }
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j) {
+          const int r = r0 + j, ri = (r & 3) + 8 * (r >> 2), lrow = AT ? TM * ri + mi : mi * 32 + ri;
+          f32x4 v;
+#pragma unroll
+          for (int tt = 0; tt < TN; ++tt) v[tt] = value(mi, tt, r);
+          *(gquad_t)(base + (lane_off + (unsigned)lrow * Mv * 4u)) = v + old[j];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+  };
+
   // C (+)= accumulators; accumulators = 0   (chunked flush, FC > 0 only)
   auto flush_tile = [&](bool accumulate) {
+    if (G::HINT == 3 && TM >= 2 && interior_block) {  // (the 32-row wavefront tile measured slower with it: 139.0 vs 141.1 TF)
+      rmw_interior(accumulate, std::integral_constant<int, 4>{}, [&](int mi, int tt, int r) { return acc[mi][tt][r]; });
+#pragma unroll
+      for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+        for (int tt = 0; tt < TN; ++tt) acc[mi][tt] = (f32x16)0.0f;
+      return;
+    }
     const unsigned ccol = col0 + wn * 128 + 4 * lo;
 #pragma unroll
     for (int mi = 0; mi < TM; ++mi) {
@@ -438,6 +480,14 @@ __global__ __launch_bounds__(G::THREADS, G::MIN_WAVES) void mfma_f32_kernel(cons
 
   // ---- tile write: lane owns 4 consecutive columns of 16 rows per accumulator row-block --------
   auto write_tile = [&](bool accumulate) {
+    if (G::HINT == 3 && TM >= 2 && interior_block) {
+      rmw_interior(accumulate, std::integral_constant<int, (TM * TN > 8 ? 4 : 8)>{}, [&](int mi, int tt, int r) {
+        float x = acc[mi][tt][r];
+        if (G::TWO_LEVEL) x += master[mi][tt][r];
+        return x;
+      });
+      return;
+    }
     const unsigned ccol = col0 + wn * 128 + 4 * lo;
     if (ccol < M) {
 #pragma unroll
@@ -791,8 +841,9 @@ void mfma_f32_geometry(int v, unsigned *bm, unsigned *bn, unsigned *bk, unsigned
 int mfma_f32_auto_variant(const Problem &p) {
   // relative efficiencies measured at 8192^3 / 16384^3 (profiles/r02z_f32_two_workgroups_per_cu.log, r02z_f32_small_tile_
   // pipelined.log): the 128x256 tile as two independent 4-wavefront workgroups per CU (33) reaches 0.98 of the 256x256
-  // kernel, the 128x128 one with pinned reads (35) 0.965
-  static const TileCandidate cands[] = {{8, 256, 256, 1, 1.00}, {33, 128, 256, 2, 0.98}, {35, 128, 128, 2, 0.965}};
+  // kernel -- 0.999 once both write C back in straight-line code (r02z_f32_straight_line_flush_on_pinned_kernels.log) --,
+  // the 128x128 one with pinned reads (35) 0.96
+  static const TileCandidate cands[] = {{8, 256, 256, 1, 1.00}, {33, 128, 256, 2, 0.995}, {35, 128, 128, 2, 0.96}};
   const int pick = pick_tile(cands, 3, p.n, p.m);
   // a launch that fits in ONE round of resident workgroups has no steady state to pipeline: the compiler-placed
   // schedule (14) is 2 % ahead there (2048^3: 125.0 vs 122.1 TF)
