@@ -33,10 +33,10 @@ nb = torch.rand((2048, 2048), device=dev)
 #      label          dtype      ops                  torch dtype     n     reps  knob          other variant   [path]
 CASES = [
     ("float split",  "float",   ("Multiply", "Add"), torch.float32, 8300, 100, "split_variant", 128, g.PATH_SPLIT),  # K = 8300: one flush + a ragged last slab
-    ("float",        "float",   ("Multiply", "Add"), torch.float32, 8192, 60, "f32_variant", 3),     # 3: no flush -> not bitwise comparable
+    ("float",        "float",   ("Multiply", "Add"), torch.float32, 8192, 60, "f32_variant", 24),    # 24: round-1 schedule of the 256x256 kernel
     ("half",         "half",    ("Multiply", "Add"), torch.float16, 16384, 150, "f16_variant", 0),
     ("half K%64=32", "half",    ("Multiply", "Add"), torch.float16, 8224, 100, "f16_variant", 0),    # plain ping-pong (K % 64 != 0)
-    ("double",       "double",  ("Multiply", "Add"), torch.float64, 4096, 40, None, None),
+    ("double",       "double",  ("Multiply", "Add"), torch.float64, 4096, 40, "f64_variant", 2),     # 2: round-1 schedule
     ("uint8_t",      "uint8_t", ("Multiply", "Add"), torch.uint8, 16384, 150, "i8_variant", 0),
     ("uint8 K%128=64", "uint8_t", ("Multiply", "Add"), torch.uint8, 8256, 100, "i8_variant", 0),
     ("min-plus",     "float",   ("Add", "Min"), torch.float32, 8192, 60, "valu_variant", 0),
@@ -65,7 +65,7 @@ for label, dtype, ops, tdt, n, reps, knob, other, *rest in CASES:
         g.set_tuning(knob, -1)
         torch.cuda.synchronize()
         same_as_other = bool(torch.equal(alt.view(torch.uint8), ref.view(torch.uint8)))
-        if not (label == "float"):
+        if True:
             assert same_as_other, f"{label}: differs from the independent schedule (variant {other})"
     bad = 0
     t0 = time.perf_counter()
