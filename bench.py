@@ -65,6 +65,16 @@ POWER_CEILING = {
 }
 
 
+# What a loop of nothing but independent MFMAs on registers sustains on this part (same probe, constant operands):
+# the clock the chip holds under that load, not the nominal 2.4 GHz the `peak` column assumes.
+MFMA_SUSTAINED = {
+    "float": {"register_only_mfma_TOps": 155.5, "clock_GHz": 2.374,
+              "source": "profiles/r02s_probe_mfma_issue_rates_and_power_ceiling.txt"},
+    "double": {"register_only_mfma_TOps": 78.1, "clock_GHz": 2.382,
+               "source": "profiles/r02s_probe_mfma_issue_rates_and_power_ceiling.txt"},
+}
+
+
 def cpu_baseline(sample_n=1024):
     """The repo's own hlslib simulation path (reference kernel sources + test-only shim) on
     float sample_n^3; this is the checker's side of the house, never the product."""
@@ -167,7 +177,8 @@ def roofline_obj(dtype, roof, peak, rows, k, m, launch_ms):
             "algorithmic_flops_per_launch": 2.0 * rows * k * m,
             "algorithmic_bytes_per_launch": float((rows * k + k * m + rows * m) * es),
             "avg_launch_ms": round(1e3 * avg_s, 4),
-            **({"power_ceiling": POWER_CEILING[dtype]} if dtype in POWER_CEILING else {})}
+            **({"power_ceiling": POWER_CEILING[dtype]} if dtype in POWER_CEILING else {}),
+            **({"mfma_sustained": MFMA_SUSTAINED[dtype]} if dtype in MFMA_SUSTAINED and roof == "mfma" else {})}
 
 
 def extra_workloads(g, torch, dev, local_rank, steps=5):
