@@ -550,14 +550,14 @@ int mm_kernel_info(const mm_config_t *cfg, unsigned n, unsigned k, unsigned m, m
     case FAM_MFMA_F32:
       mm::mfma_f32_geometry(f32_variant_for(p), &r.tile_n, &r.tile_m, &r.tile_k, &r.wavefronts);
       r.inst_n = 32; r.inst_m = 32; r.inst_k = 2; r.ops_per_clk_per_cu = 256.0;   // 64 FLOP/clk/SIMD
-      r.measured_issue_efficiency = 0.934;  // profiles/r01_pmc_f32_default.json
+      r.measured_issue_efficiency = 0.967;  // 152.2 TF of 157.3 (profiles/r02z_f32_scalar_base_dma.log)
       break;
     case FAM_MFMA_F64:
       if (mm::mfma_f64_tile(p) == 1) { r.tile_n = 128; r.tile_m = 128; r.wavefronts = 4; }
       else { r.tile_n = 256; r.tile_m = 128; r.wavefronts = 8; }
       r.tile_k = 16;
       r.inst_n = 16; r.inst_m = 16; r.inst_k = 4; r.ops_per_clk_per_cu = 128.0;
-      r.measured_issue_efficiency = 0.95;  // pinned schedule: 74.5 TF of 78.6 (profiles/r02zz_bench_n1_with_workloads.json)
+      r.measured_issue_efficiency = 0.97;  // pinned schedule + scalar-base DMA: 76.4 TF of 78.6 (profiles/r02z_f64_scalar_base_dma.log)
       break;
     case FAM_MFMA_F16:
       if (mm::mfma_f16_tile(p) == 4) { r.tile_n = 128; r.tile_m = 256; r.wavefronts = 4; }

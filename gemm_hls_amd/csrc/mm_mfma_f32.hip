@@ -171,6 +171,44 @@ __global__ __launch_bounds__(G::THREADS, G::MIN_WAVES) void mfma_f32_kernel(cons
     if (G::HINT == 8) asm volatile("s_mov_b64 exec, -1" ::: "memory");
   };
 
+  // HINT 9 (row-major A): the DMA in its scalar-base form -- uniform 64-bit base in SGPRs + a constant 32-bit per-lane
+  // offset, as the half kernels use it: one address VGPR per lane instead of two, no per-slab 64-bit VALU address
+  // arithmetic.  A slab start past K - BK (beyond the end, or the partial last slab) is clamped to K - BK, uniformly:
+  // a partial last slab then sits in the SECOND half of its buffer (see the last-slab loop).  Needs K >= BK.
+  constexpr bool SDMA = G::HINT == 9 && !AT;
+  unsigned voa[G::LA], vob[G::LB];
+  if (SDMA) {
+#pragma unroll
+    for (int i = 0; i < G::LA; ++i) {
+      const unsigned slot = (wave + G::NW * i) * 64 + lane, row = slot / CPR;
+      voa[i] = (min(row0 + row, N - 1) - row0) * K * 4u + a_kchunk[i] * 16u;
+    }
+#pragma unroll
+    for (int i = 0; i < G::LB; ++i) vob[i] = b_krow[i] * M * 4u + (b_col[i] - col0) * 4u;
+  }
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
+  auto dma_piece_s = [&](unsigned buf, unsigned k0, int i) {
+    const unsigned kc = min(k0, K - BK);
+    const bool is_a = i < G::LA;
+    const int j = is_a ? i : i - G::LA;
+    unsigned long long base = is_a ? (unsigned long long)(A + (size_t)row0 * K + kc) : (unsigned long long)(B + (size_t)kc * M + col0);
+    const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)base), bhi = __builtin_amdgcn_readfirstlane((unsigned)(base >> 32));
+    base = ((unsigned long long)bhi << 32) | blo;
+    const unsigned la = lds_base + buf * G::STAGE_BYTES + (is_a ? 0 : G::A_BYTES) + (wave + G::NW * j) * 1024;
+    const unsigned vo = is_a ? voa[j] : vob[j];
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(vo), "s"(base), "s"(la) : "memory");
+  };
+  auto stage_any = [&](unsigned buf, unsigned k0) {
+    if constexpr (SDMA) {
+#pragma unroll
+      for (int i = 0; i < G::LA + G::LB; ++i) dma_piece_s(buf, k0, i);
+    } else {
+      stage(buf, k0);
+    }
+  };
+
   // ---- per-lane fragment addresses (bytes inside a stage) -------------------------------------
   // A: row = wm*TM*32 + mi*32 + lo; chunk = (2*kg + hi) ^ swz(row) = (2*kg) ^ (hi ^ swz(lo))
   const unsigned a_swz = hi ^ ((lo >> G::SWZ_SHIFT) & (CPR - 1));
@@ -260,7 +298,7 @@ __global__ __launch_bounds__(G::THREADS, G::MIN_WAVES) void mfma_f32_kernel(cons
 
   // C (+)= accumulators; accumulators = 0   (chunked flush, FC > 0 only)
   auto flush_tile = [&](bool accumulate) {
-    if (G::HINT == 3 && TM >= 2 && interior_block) {  // (the 32-row wavefront tile measured slower with it: 139.0 vs 141.1 TF)
+    if ((G::HINT == 3 || G::HINT == 9) && TM >= 2 && interior_block) {  // (the 32-row wavefront tile measured slower with it: 139.0 vs 141.1 TF)
       rmw_interior(accumulate, std::integral_constant<int, 4>{}, [&](int mi, int tt, int r) { return acc[mi][tt][r]; });
 #pragma unroll
       for (int mi = 0; mi < TM; ++mi)
@@ -297,7 +335,7 @@ __global__ __launch_bounds__(G::THREADS, G::MIN_WAVES) void mfma_f32_kernel(cons
   // (it lands in a ring slot nobody reads again); this keeps the steady state branch-free and
   // the vmcnt immediates constant.
 #pragma unroll
-  for (int s = 0; s < NS; ++s) stage(s, s * BK);
+  for (int s = 0; s < NS; ++s) stage_any(s, s * BK);
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 1) * L) : "memory");
   __builtin_amdgcn_s_barrier();
 
@@ -380,6 +418,32 @@ __global__ __launch_bounds__(G::THREADS, G::MIN_WAVES) void mfma_f32_kernel(cons
           asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NS - 2) * L) : "memory");
           if (G::HINT != 4) __builtin_amdgcn_s_barrier();
           __builtin_amdgcn_sched_barrier(0);
+          if constexpr (SDMA) {
+            // the DMA pieces are inline asm (the scheduler cannot classify them): one MFMA, one piece, by hand; then
+            // the reads of the next slab's first group one-per-MFMA as in the builtin form
+            static_assert(!EARLY, "scalar-base DMA is wired for the wide wavefront tiles only");
+            auto mfma_one = [&](int idx) {
+              const int p = 2 + idx / (TM * TN), mi = (idx / TN) % TM, tt = idx % TN;
+              acc[mi][tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(afc[mi][p], bfc[p][tt], acc[mi][tt], 0, 0, 0);
+            };
+#pragma unroll
+            for (int i = 0; i < L; ++i) {
+              mfma_one(i);
+              dma_piece_s(buf, (t + NS) * BK, i);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+            load_frags((t + 1) % NS, 0, afn, bfn);
+#pragma unroll
+            for (int i = L; i < NM; ++i) mfma_one(i);
+#pragma unroll
+            for (int i = 0; i < NR; ++i) {
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+              __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, NM - L - NR, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            continue;
+          }
           if (DO_DMA) stage(buf, (t + NS) * BK);
           if (DO_READS) load_frags((t + 1) % NS, 0, afn, bfn);
           if (EARLY) mfma_half(afc, bfc, 0);
@@ -468,8 +532,10 @@ __global__ __launch_bounds__(G::THREADS, G::MIN_WAVES) void mfma_f32_kernel(cons
   {
     const unsigned t = num_tiles - 1;
     const int groups = (int)((K - t * BK) / 8);
+    // scalar-base DMA fetched a partial last slab as the LAST BK k of the matrix: its k-groups start further in
+    const int shift = SDMA ? G::KG - groups : 0;
     for (int kg = 0; kg < groups; ++kg) {
-      load_frags(t % NS, kg, af0, bf0);
+      load_frags(t % NS, kg + shift, af0, bf0);
       mfma_group(af0, bf0);
     }
   }
@@ -480,7 +546,7 @@ __global__ __launch_bounds__(G::THREADS, G::MIN_WAVES) void mfma_f32_kernel(cons
 
   // ---- tile write: lane owns 4 consecutive columns of 16 rows per accumulator row-block --------
   auto write_tile = [&](bool accumulate) {
-    if (G::HINT == 3 && TM >= 2 && interior_block) {
+    if ((G::HINT == 3 || G::HINT == 9) && TM >= 2 && interior_block) {
       rmw_interior(accumulate, std::integral_constant<int, (TM * TN > 8 ? 4 : 8)>{}, [&](int mi, int tt, int r) {
         float x = acc[mi][tt][r];
         if (G::TWO_LEVEL) x += master[mi][tt][r];
@@ -755,6 +821,10 @@ using V32 = Geo<2, 4, 2, 16, 2, false, 1, 0, false, false, 8>;    // ABLATION: V
 using V33 = Geo<2, 2, 2, 16, 2, false, 1, 256, false, false, 3>;  // V15 (128x256x16, 4 waves, 2 workgroups per CU) + pipelined reads
 using V34 = Geo<2, 2, 2, 16, 3, false, 1, 256, false, false, 3>;  // the same with a ring of 3 (72 KiB LDS)
 using V35 = Geo<1, 4, 1, 32, 2, false, 1, 128, false, false, 3>;  // V14 (128x128x32, 2 workgroups per CU) + pipelined reads
+using V8S = Geo<2, 4, 2, 16, 2, false, 1, 256, false, false, 9>; // V8 with the DMA in its scalar-base form: what variant 8 runs for K >= 16
+using V36 = V8;                                                   // variant 36 pins the builtin (vector-address) DMA form of V8
+using V37 = Geo<2, 4, 2, 16, 2, false, 1, 0, false, false, 9>;    // V25 (no flush) with scalar-base DMA
+using V33S = Geo<2, 2, 2, 16, 2, false, 1, 256, false, false, 9>; // V33 with scalar-base DMA: what variant 33 runs for K >= 16
 
 }  // namespace
 
@@ -795,9 +865,11 @@ const char *mfma_f32_name(int v) {
     case 30: return "mfma_f32_256x256x16_w8_piperead_ABLATION_no_reads";
     case 31: return "mfma_f32_256x256x16_w8_piperead_ABLATION_mfma_only";
     case 32: return "mfma_f32_256x256x16_w8_piperead_ABLATION_dma_exec0";
-    case 33: return "mfma_f32_128x256x16_w4_flush4096_2percu_piperead";
-    case 34: return "mfma_f32_128x256x16_w4_flush4096_2percu_piperead_ns3";
+    case 33: return "mfma_f32_128x256x16_w4x2_flush4096";  // two independent 4-wavefront workgroups per CU
+    case 34: return "mfma_f32_128x256x16_w4x2_flush4096_ns3";
     case 35: return "mfma_f32_128x128x32_w4_flush4096_piperead";
+    case 36: return "mfma_f32_256x256x16_w8_flush4096_vdma";
+    case 37: return "mfma_f32_256x256x16_w8_sdma";
   }
   return "?";
 }
@@ -829,6 +901,8 @@ void mfma_f32_geometry(int v, unsigned *bm, unsigned *bn, unsigned *bk, unsigned
     case 33: return geo_of<V33>(bm, bn, bk, waves);
     case 34: return geo_of<V34>(bm, bn, bk, waves);
     case 35: return geo_of<V35>(bm, bn, bk, waves);
+    case 36: return geo_of<V36>(bm, bn, bk, waves);
+    case 37: return geo_of<V37>(bm, bn, bk, waves);
     default: return geo_of<V8>(bm, bn, bk, waves);
   }
 }
@@ -843,7 +917,8 @@ int mfma_f32_auto_variant(const Problem &p) {
   // pipelined.log): the 128x256 tile as two independent 4-wavefront workgroups per CU (33) reaches 0.98 of the 256x256
   // kernel -- 0.999 once both write C back in straight-line code (r02z_f32_straight_line_flush_on_pinned_kernels.log) --,
   // the 128x128 one with pinned reads (35) 0.96
-  static const TileCandidate cands[] = {{8, 256, 256, 1, 1.00}, {33, 128, 256, 2, 0.995}, {35, 128, 128, 2, 0.96}};
+  // end of round 2, both with scalar-base DMA: 33 = 152.2 TF, 8 = 150.8 TF at 16384^3 (r02z_f32_scalar_base_dma.log)
+  static const TileCandidate cands[] = {{33, 128, 256, 2, 1.00}, {8, 256, 256, 1, 0.991}, {35, 128, 128, 2, 0.955}};
   const int pick = pick_tile(cands, 3, p.n, p.m);
   // a launch that fits in ONE round of resident workgroups has no steady state to pipeline: the compiler-placed
   // schedule (14) is 2 % ahead there (2048^3: 125.0 vs 122.1 TF)
@@ -869,7 +944,7 @@ int launch_mfma_f32(hipStream_t s, const Problem &p, int variant) {
     case 5: return launch_geo<V5>(s, p);
     case 6: return launch_geo<V6>(s, p);
     case 7: return launch_geo<V7>(s, p);
-    case 8: return launch_geo<V8>(s, p);
+    case 8: return p.k >= 16 ? launch_geo<V8S>(s, p) : launch_geo<V8>(s, p);
     case 9: return launch_geo<V9>(s, p);
     case 10: return launch_geo<V10>(s, p);
     case 11: return launch_geo<V11>(s, p);
@@ -894,9 +969,11 @@ int launch_mfma_f32(hipStream_t s, const Problem &p, int variant) {
     case 30: return tuning(TUNE_ABLATIONS) == 1 ? launch_geo<V30>(s, p) : kErrNotSupported;
     case 31: return tuning(TUNE_ABLATIONS) == 1 ? launch_geo<V31>(s, p) : kErrNotSupported;
     case 32: return tuning(TUNE_ABLATIONS) == 1 ? launch_geo<V32>(s, p) : kErrNotSupported;
-    case 33: return launch_geo<V33>(s, p);
+    case 33: return p.k >= 16 ? launch_geo<V33S>(s, p) : launch_geo<V33>(s, p);
     case 34: return launch_geo<V34>(s, p);
     case 35: return launch_geo<V35>(s, p);
+    case 36: return launch_geo<V36>(s, p);
+    case 37: return p.k >= 16 ? launch_geo<V37>(s, p) : launch_geo<V25>(s, p);
   }
   return kErrNotSupported;
 }

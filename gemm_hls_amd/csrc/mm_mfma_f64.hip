@@ -103,6 +103,37 @@ __global__ __launch_bounds__(G::THREADS, 2) void mfma_f64_kernel(  // 2 wavefron
     }
   };
 
+  // Scalar-base form of the same DMA (row-major A, K >= BK): uniform 64-bit base in SGPRs + a constant 32-bit per-lane
+  // offset -- one address VGPR per lane instead of two, no per-slab 64-bit VALU address arithmetic.  On the fp32 kernel
+  // this removed most of the DMA instructions' issue cost (+2.5 %, mm_mfma_f32.hip).  A slab start past K - BK (beyond
+  // the end, or the partial last slab) is clamped to K - BK uniformly: a partial last slab sits in the SECOND half of
+  // its buffer (see the last-slab loop).  K < BK never reaches a PIPE geometry (launch_mfma_f64).
+  constexpr bool SDMA = G::PIPE && !AT;
+  unsigned voa[G::LA], vob[G::LB];
+  if (SDMA) {
+#pragma unroll
+    for (int i = 0; i < G::LA; ++i) {
+      const unsigned slot = (wave + G::NW * i) * 64 + lane, row = slot / CPR;
+      voa[i] = (min(row0 + row, N - 1) - row0) * K * 8u + a_kchunk[i] * 16u;
+    }
+#pragma unroll
+    for (int i = 0; i < G::LB; ++i) vob[i] = b_krow[i] * M * 8u + (b_col[i] - col0) * 8u;
+  }
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
+  auto dma_piece_s = [&](unsigned buf, unsigned k0, int i) {
+    const unsigned kc = min(k0, K - BK);
+    const bool is_a = i < G::LA;
+    const int j = is_a ? i : i - G::LA;
+    unsigned long long base = is_a ? (unsigned long long)(A + (size_t)row0 * K + kc) : (unsigned long long)(B + (size_t)kc * M + col0);
+    const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)base), bhi = __builtin_amdgcn_readfirstlane((unsigned)(base >> 32));
+    base = ((unsigned long long)bhi << 32) | blo;
+    const unsigned la = lds_base + buf * G::STAGE_BYTES + (is_a ? 0 : G::A_BYTES) + (wave + G::NW * j) * 1024;
+    const unsigned vo = is_a ? voa[j] : vob[j];
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(vo), "s"(base), "s"(la) : "memory");
+  };
+
   // A: row = wm*64 + mi*16 + lo; chunk = (4*kg + g4) ^ swz(lo)
   const unsigned a_swz = (lo >> 1) & (CPR - 1);
   // K x N layout: image [k][row]; a lane reads 2 consecutive rows of k-row 2*g4 + p, so row
@@ -156,8 +187,16 @@ __global__ __launch_bounds__(G::THREADS, 2) void mfma_f64_kernel(  // 2 wavefron
 
   const unsigned num_tiles = (K + BK - 1) / BK;
   constexpr int L = G::LA + G::LB;
+  constexpr bool sdma = SDMA;          // the launcher sends K < BK to the non-PIPE geometry
 #pragma unroll
-  for (int s = 0; s < NS; ++s) stage(s, s * BK);
+  for (int s = 0; s < NS; ++s) {
+    if constexpr (sdma) {
+#pragma unroll
+      for (int i = 0; i < L; ++i) dma_piece_s(s, s * BK, i);
+    } else {
+      stage(s, s * BK);
+    }
+  }
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 1) * L) : "memory");
   __builtin_amdgcn_s_barrier();
 
@@ -198,10 +237,34 @@ __global__ __launch_bounds__(G::THREADS, 2) void mfma_f64_kernel(  // 2 wavefron
       asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NS - 2) * L) : "memory");
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
+      static_assert(L + NR <= NM, "post-barrier half group too short for the interleave");
+      if constexpr (sdma) {
+        // the DMA pieces are inline asm (the scheduler cannot classify them): one MFMA, one piece, by hand
+        auto mfma_one = [&](int idx) {  // idx-th MFMA of mfma_half(af1, bf1, 1)
+          const int mi = idx / (2 * TP), pr = (idx / 2) % TP, h = idx % 2;
+          acc[mi][pr][h] = __builtin_amdgcn_mfma_f64_16x16x4f64(af1[mi][1], bf1[1][pr][h], acc[mi][pr][h], 0, 0, 0);
+        };
+#pragma unroll
+        for (int i = 0; i < L; ++i) {
+          mfma_one(i);
+          dma_piece_s(buf, (t + NS) * BK, i);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        load_frags((t + 1) % NS, 0, af0, bf0);
+#pragma unroll
+        for (int i = L; i < NM; ++i) mfma_one(i);
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, NM - L - NR, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        continue;
+      }
       stage(buf, (t + NS) * BK);
       load_frags((t + 1) % NS, 0, af0, bf0);
       mfma_half(af1, bf1, 1);
-      static_assert(L + NR <= NM, "post-barrier half group too short for the interleave");
 #pragma unroll
       for (int i = 0; i < L; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -227,8 +290,9 @@ __global__ __launch_bounds__(G::THREADS, 2) void mfma_f64_kernel(  // 2 wavefron
   {
     const unsigned t = num_tiles - 1;
     const int groups = (int)((K - t * BK) / 8);
+    const int shift = sdma ? G::KG - groups : 0;  // scalar-base DMA fetched a partial last slab as the LAST BK k
     for (int kg = 0; kg < groups; ++kg) {
-      load_frags(t % NS, kg, af0, bf0);
+      load_frags(t % NS, kg + shift, af0, bf0);
       mfma_group(af0, bf0);
     }
   }
@@ -294,7 +358,7 @@ int mfma_f64_tile(const Problem &p) {  // 0: 256x128, 1: 128x128
 
 int launch_mfma_f64(hipStream_t s, const Problem &p) {
   if (!mfma_f64_serves(p)) return kErrNotSupported;
-  if (tuning(TUNE_F64_VARIANT) >= 2) return mfma_f64_tile(p) == 1 ? launch_d<D1R1>(s, p) : launch_d<D0R1>(s, p);
+  if (tuning(TUNE_F64_VARIANT) >= 2 || p.k < 16) return mfma_f64_tile(p) == 1 ? launch_d<D1R1>(s, p) : launch_d<D0R1>(s, p);
   return mfma_f64_tile(p) == 1 ? launch_d<D1>(s, p) : launch_d<D0>(s, p);
 }
 

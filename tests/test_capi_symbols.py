@@ -98,7 +98,7 @@ def test_tuning_knobs_are_library_state_not_environment(monkeypatch):
         assert g.kernel_name(g.make_config("float"), 4096, 4096, 4096) == "mfma_f32_256x256x16_w8"
     finally:
         g.set_tuning("f32_variant", -1)
-    assert g.kernel_name(g.make_config("float"), 16384, 16384, 16384) == "mfma_f32_256x256x16_w8_flush4096"
+    assert g.kernel_name(g.make_config("float"), 16384, 16384, 16384) == "mfma_f32_128x256x16_w4x2_flush4096"
     with pytest.raises(g.MMError, match="unknown tuning knob"):
         g.set_tuning("no_such_knob", 1)
 
@@ -115,5 +115,5 @@ def test_tuning_environment_is_read_at_first_use():
 
 def test_kernel_info_binding():
     info = g.kernel_info(g.make_config("float"), 16384, 16384, 16384)
-    assert (info.tile_n, info.tile_m, info.tile_k, info.wavefronts) == (256, 256, 16, 8)
+    assert (info.tile_n, info.tile_m, info.tile_k, info.wavefronts) == (128, 256, 16, 4)   # two such workgroups per CU
     assert info.compute_units == 256 and info.max_clock_mhz == 2400.0

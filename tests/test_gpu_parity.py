@@ -47,7 +47,7 @@ def test_f32_mfma_default_vs_blas_and_exact(shape):
     assert np.max(np.abs(c - exact) / exact) < F32_TOL
 
 
-@pytest.mark.parametrize("variant", list(range(28)) + [33, 34, 35])
+@pytest.mark.parametrize("variant", list(range(28)) + [33, 34, 35, 36, 37])
 @pytest.mark.parametrize("shape", [(513, 528, 528), (300, 64, 272), (256, 8, 4), (37, 32, 48), (300, 8208, 272)],
                          ids=lambda s: "x".join(map(str, s)))
 def test_f32_mfma_every_variant(variant, shape):

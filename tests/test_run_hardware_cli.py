@@ -187,9 +187,9 @@ def test_print_specifications_cli_and_model():
     out = r.stdout
     assert "Number of operations: 8796093022208" in out            # 2*N*K*M (src/PrintSpecifications.cpp:40-41)
     assert "Ideal performance:    157286 GOp/s" in out              # 256 CU x 256 FLOP/clk x 2.4 GHz
-    assert "Memory tile size: 256x256" in out and "Frequency:            2400 MHz" in out
+    assert "Memory tile size: 128x256" in out and "Frequency:            2400 MHz" in out   # two such workgroups per CU
     comm = int(re.search(r"Communication volume: (\d+)", out).group(1))
-    assert comm == 16384 * 16384 * (1 + 16384 // 256 + 16384 // 256)  # N*M*(1 + K/TN + K/TM), :72-74
+    assert comm == 16384 * 16384 * (1 + 16384 // 128 + 16384 // 256)  # N*M*(1 + K/TN + K/TM), :72-74
     r2 = run(exe, 16384, 16384, 16384, 1200)
     assert "Ideal performance:    78643" in r2.stdout               # scales with the routed frequency
 
