@@ -420,10 +420,11 @@ __global__ __launch_bounds__(G::THREADS, G::MIN_WAVES) void mfma_f32_kernel(cons
           __builtin_amdgcn_sched_barrier(0);
           if constexpr (SDMA) {
             // the DMA pieces are inline asm (the scheduler cannot classify them): one MFMA, one piece, by hand; then
-            // the reads of the next slab's first group one-per-MFMA as in the builtin form
-            static_assert(!EARLY, "scalar-base DMA is wired for the wide wavefront tiles only");
+            // the reads of the next slab's first group one-per-MFMA as in the builtin form.  EARLY geometries spread
+            // this over the whole last group (the barrier came before its first half), the others over its second half.
+            constexpr int TOTAL = (EARLY ? 2 : 1) * NM, P0 = EARLY ? 0 : 2;
             auto mfma_one = [&](int idx) {
-              const int p = 2 + idx / (TM * TN), mi = (idx / TN) % TM, tt = idx % TN;
+              const int p = P0 + idx / (TM * TN), mi = (idx / TN) % TM, tt = idx % TN;
               acc[mi][tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(afc[mi][p], bfc[p][tt], acc[mi][tt], 0, 0, 0);
             };
 #pragma unroll
@@ -434,13 +435,13 @@ __global__ __launch_bounds__(G::THREADS, G::MIN_WAVES) void mfma_f32_kernel(cons
             }
             load_frags((t + 1) % NS, 0, afn, bfn);
 #pragma unroll
-            for (int i = L; i < NM; ++i) mfma_one(i);
+            for (int i = L; i < TOTAL; ++i) mfma_one(i);
 #pragma unroll
             for (int i = 0; i < NR; ++i) {
               __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
               __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             }
-            __builtin_amdgcn_sched_group_barrier(0x008, NM - L - NR, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, TOTAL - L - NR, 0);
             __builtin_amdgcn_sched_barrier(0);
             continue;
           }
@@ -825,6 +826,7 @@ using V8S = Geo<2, 4, 2, 16, 2, false, 1, 256, false, false, 9>; // V8 with the 
 using V36 = V8;                                                   // variant 36 pins the builtin (vector-address) DMA form of V8
 using V37 = Geo<2, 4, 2, 16, 2, false, 1, 0, false, false, 9>;    // V25 (no flush) with scalar-base DMA
 using V33S = Geo<2, 2, 2, 16, 2, false, 1, 256, false, false, 9>; // V33 with scalar-base DMA: what variant 33 runs for K >= 16
+using V35S = Geo<1, 4, 1, 32, 2, false, 1, 128, false, false, 9>; // V35 with scalar-base DMA: what variant 35 runs for K >= 32
 
 }  // namespace
 
@@ -867,7 +869,7 @@ const char *mfma_f32_name(int v) {
     case 32: return "mfma_f32_256x256x16_w8_piperead_ABLATION_dma_exec0";
     case 33: return "mfma_f32_128x256x16_w4x2_flush4096";  // two independent 4-wavefront workgroups per CU
     case 34: return "mfma_f32_128x256x16_w4x2_flush4096_ns3";
-    case 35: return "mfma_f32_128x128x32_w4_flush4096_piperead";
+    case 35: return "mfma_f32_128x128x32_w4x2_flush4096";
     case 36: return "mfma_f32_256x256x16_w8_flush4096_vdma";
     case 37: return "mfma_f32_256x256x16_w8_sdma";
   }
@@ -913,17 +915,12 @@ void mfma_f32_geometry(int v, unsigned *bm, unsigned *bn, unsigned *bk, unsigned
 // the candidate with the smallest estimated time = (workgroups the busiest CU runs) x tile area /
 // relative efficiency.
 int mfma_f32_auto_variant(const Problem &p) {
-  // relative efficiencies measured at 8192^3 / 16384^3 (profiles/r02z_f32_two_workgroups_per_cu.log, r02z_f32_small_tile_
-  // pipelined.log): the 128x256 tile as two independent 4-wavefront workgroups per CU (33) reaches 0.98 of the 256x256
-  // kernel -- 0.999 once both write C back in straight-line code (r02z_f32_straight_line_flush_on_pinned_kernels.log) --,
-  // the 128x128 one with pinned reads (35) 0.96
-  // end of round 2, both with scalar-base DMA: 33 = 152.2 TF, 8 = 150.8 TF at 16384^3 (r02z_f32_scalar_base_dma.log)
-  static const TileCandidate cands[] = {{33, 128, 256, 2, 1.00}, {8, 256, 256, 1, 0.991}, {35, 128, 128, 2, 0.955}};
-  const int pick = pick_tile(cands, 3, p.n, p.m);
-  // a launch that fits in ONE round of resident workgroups has no steady state to pipeline: the compiler-placed
-  // schedule (14) is 2 % ahead there (2048^3: 125.0 vs 122.1 TF)
-  const unsigned long long tiles = (unsigned long long)((p.n + 127) / 128) * ((p.m + 127) / 128);
-  return pick == 35 && tiles <= 512 ? 14 : pick;
+  // relative efficiencies at 16384^3 at the end of round 2, all three with the pinned schedule and scalar-base DMA:
+  // 128x256 as two 4-wavefront workgroups per CU (33) 152.2 TF, 256x256 / 8 wavefronts (8) 150.8, 128x128x32 (35) 151.2
+  // (profiles/r02z_f32_scalar_base_dma.log, r02z_f32_small_tile_scalar_base_dma.log); small and mid-size shapes:
+  // r02z_f32_small_shapes_after_scalar_base_dma.log
+  static const TileCandidate cands[] = {{33, 128, 256, 2, 1.00}, {8, 256, 256, 1, 0.991}, {35, 128, 128, 2, 0.993}};
+  return pick_tile(cands, 3, p.n, p.m);
 }
 
 bool mfma_f32_serves(const Problem &p) {
@@ -971,7 +968,7 @@ int launch_mfma_f32(hipStream_t s, const Problem &p, int variant) {
     case 32: return tuning(TUNE_ABLATIONS) == 1 ? launch_geo<V32>(s, p) : kErrNotSupported;
     case 33: return p.k >= 16 ? launch_geo<V33S>(s, p) : launch_geo<V33>(s, p);
     case 34: return launch_geo<V34>(s, p);
-    case 35: return launch_geo<V35>(s, p);
+    case 35: return p.k >= 32 ? launch_geo<V35S>(s, p) : launch_geo<V35>(s, p);
     case 36: return launch_geo<V36>(s, p);
     case 37: return p.k >= 16 ? launch_geo<V37>(s, p) : launch_geo<V25>(s, p);
   }
