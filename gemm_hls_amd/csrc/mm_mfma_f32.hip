@@ -171,17 +171,18 @@ __global__ __launch_bounds__(G::THREADS, G::MIN_WAVES) void mfma_f32_kernel(cons
     if (G::HINT == 8) asm volatile("s_mov_b64 exec, -1" ::: "memory");
   };
 
-  // HINT 9 (row-major A): the DMA in its scalar-base form -- uniform 64-bit base in SGPRs + a constant 32-bit per-lane
+  // HINT 9: the DMA in its scalar-base form -- uniform 64-bit base in SGPRs + a constant 32-bit per-lane
   // offset, as the half kernels use it: one address VGPR per lane instead of two, no per-slab 64-bit VALU address
   // arithmetic.  A slab start past K - BK (beyond the end, or the partial last slab) is clamped to K - BK, uniformly:
   // a partial last slab then sits in the SECOND half of its buffer (see the last-slab loop).  Needs K >= BK.
-  constexpr bool SDMA = G::HINT == 9 && !AT;
+  constexpr bool SDMA = G::HINT == 9;
   unsigned voa[G::LA], vob[G::LB];
   if (SDMA) {
 #pragma unroll
     for (int i = 0; i < G::LA; ++i) {
       const unsigned slot = (wave + G::NW * i) * 64 + lane, row = slot / CPR;
-      voa[i] = (min(row0 + row, N - 1) - row0) * K * 4u + a_kchunk[i] * 16u;
+      if (AT) voa[i] = a_kchunk[i] * N * 4u + ((unsigned)a_row_off[i] - row0) * 4u;   // K x N: k-row, clamped column
+      else voa[i] = (min(row0 + row, N - 1) - row0) * K * 4u + a_kchunk[i] * 16u;
     }
 #pragma unroll
     for (int i = 0; i < G::LB; ++i) vob[i] = b_krow[i] * M * 4u + (b_col[i] - col0) * 4u;
@@ -191,7 +192,8 @@ __global__ __launch_bounds__(G::THREADS, G::MIN_WAVES) void mfma_f32_kernel(cons
     const unsigned kc = min(k0, K - BK);
     const bool is_a = i < G::LA;
     const int j = is_a ? i : i - G::LA;
-    unsigned long long base = is_a ? (unsigned long long)(A + (size_t)row0 * K + kc) : (unsigned long long)(B + (size_t)kc * M + col0);
+    unsigned long long base = !is_a ? (unsigned long long)(B + (size_t)kc * M + col0)
+                              : AT ? (unsigned long long)(A + (size_t)kc * N + row0) : (unsigned long long)(A + (size_t)row0 * K + kc);
     const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)base), bhi = __builtin_amdgcn_readfirstlane((unsigned)(base >> 32));
     base = ((unsigned long long)bhi << 32) | blo;
     const unsigned la = lds_base + buf * G::STAGE_BYTES + (is_a ? 0 : G::A_BYTES) + (wave + G::NW * j) * 1024;
@@ -930,7 +932,7 @@ bool mfma_f32_serves(const Problem &p) {
 
 int launch_mfma_f32(hipStream_t s, const Problem &p, int variant) {
   if (!mfma_f32_serves(p)) return kErrNotSupported;
-  if (p.a_transposed) return launch_geo_at<V8>(s, p);
+  if (p.a_transposed) return p.k >= 16 ? launch_geo_at<V8S>(s, p) : launch_geo_at<V8>(s, p);
   if (variant < 0) variant = mfma_f32_auto_variant(p);
   switch (variant) {
     case 0: return launch_geo<V0>(s, p);

@@ -103,18 +103,19 @@ __global__ __launch_bounds__(G::THREADS, 2) void mfma_f64_kernel(  // 2 wavefron
     }
   };
 
-  // Scalar-base form of the same DMA (row-major A, K >= BK): uniform 64-bit base in SGPRs + a constant 32-bit per-lane
+  // Scalar-base form of the same DMA (K >= BK): uniform 64-bit base in SGPRs + a constant 32-bit per-lane
   // offset -- one address VGPR per lane instead of two, no per-slab 64-bit VALU address arithmetic.  On the fp32 kernel
   // this removed most of the DMA instructions' issue cost (+2.5 %, mm_mfma_f32.hip).  A slab start past K - BK (beyond
   // the end, or the partial last slab) is clamped to K - BK uniformly: a partial last slab sits in the SECOND half of
   // its buffer (see the last-slab loop).  K < BK never reaches a PIPE geometry (launch_mfma_f64).
-  constexpr bool SDMA = G::PIPE && !AT;
+  constexpr bool SDMA = G::PIPE;
   unsigned voa[G::LA], vob[G::LB];
   if (SDMA) {
 #pragma unroll
     for (int i = 0; i < G::LA; ++i) {
       const unsigned slot = (wave + G::NW * i) * 64 + lane, row = slot / CPR;
-      voa[i] = (min(row0 + row, N - 1) - row0) * K * 8u + a_kchunk[i] * 16u;
+      if (AT) voa[i] = a_kchunk[i] * N * 8u + ((unsigned)a_row_off[i] - row0) * 8u;   // K x N: k-row, clamped column
+      else voa[i] = (min(row0 + row, N - 1) - row0) * K * 8u + a_kchunk[i] * 16u;
     }
 #pragma unroll
     for (int i = 0; i < G::LB; ++i) vob[i] = b_krow[i] * M * 8u + (b_col[i] - col0) * 8u;
@@ -124,7 +125,8 @@ __global__ __launch_bounds__(G::THREADS, 2) void mfma_f64_kernel(  // 2 wavefron
     const unsigned kc = min(k0, K - BK);
     const bool is_a = i < G::LA;
     const int j = is_a ? i : i - G::LA;
-    unsigned long long base = is_a ? (unsigned long long)(A + (size_t)row0 * K + kc) : (unsigned long long)(B + (size_t)kc * M + col0);
+    unsigned long long base = !is_a ? (unsigned long long)(B + (size_t)kc * M + col0)
+                              : AT ? (unsigned long long)(A + (size_t)kc * N + row0) : (unsigned long long)(A + (size_t)row0 * K + kc);
     const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)base), bhi = __builtin_amdgcn_readfirstlane((unsigned)(base >> 32));
     base = ((unsigned long long)bhi << 32) | blo;
     const unsigned la = lds_base + buf * G::STAGE_BYTES + (is_a ? 0 : G::A_BYTES) + (wave + G::NW * j) * 1024;
