@@ -930,9 +930,16 @@ bool mfma_f32_serves(const Problem &p) {
   return !p.a_transposed || (p.n >= 4 && p.n % 4 == 0);  // K x N A is DMA'd in 16-B chunks along N
 }
 
+// The scalar-base DMA form addresses a tile's rows with 32-bit byte offsets from a 64-bit base: 256 rows x K x 4 B (and
+// 32 k-rows x M x 4 B for B, K x N A) must stay below 4 GiB; absurdly long rows fall back to the vector-address kernels.
+static bool sdma_fits(const Problem &p, unsigned bk) {
+  const unsigned long long span = 256ull * (p.a_transposed ? 1ull : p.k) * 4ull, spanb = 32ull * (p.m > p.n ? p.m : p.n) * 4ull;
+  return p.k >= bk && span < (1ull << 32) && spanb < (1ull << 32);
+}
+
 int launch_mfma_f32(hipStream_t s, const Problem &p, int variant) {
   if (!mfma_f32_serves(p)) return kErrNotSupported;
-  if (p.a_transposed) return p.k >= 16 ? launch_geo_at<V8S>(s, p) : launch_geo_at<V8>(s, p);
+  if (p.a_transposed) return sdma_fits(p, 16) ? launch_geo_at<V8S>(s, p) : launch_geo_at<V8>(s, p);
   if (variant < 0) variant = mfma_f32_auto_variant(p);
   switch (variant) {
     case 0: return launch_geo<V0>(s, p);
@@ -943,7 +950,7 @@ int launch_mfma_f32(hipStream_t s, const Problem &p, int variant) {
     case 5: return launch_geo<V5>(s, p);
     case 6: return launch_geo<V6>(s, p);
     case 7: return launch_geo<V7>(s, p);
-    case 8: return p.k >= 16 ? launch_geo<V8S>(s, p) : launch_geo<V8>(s, p);
+    case 8: return sdma_fits(p, 16) ? launch_geo<V8S>(s, p) : launch_geo<V8>(s, p);
     case 9: return launch_geo<V9>(s, p);
     case 10: return launch_geo<V10>(s, p);
     case 11: return launch_geo<V11>(s, p);
@@ -968,11 +975,11 @@ int launch_mfma_f32(hipStream_t s, const Problem &p, int variant) {
     case 30: return tuning(TUNE_ABLATIONS) == 1 ? launch_geo<V30>(s, p) : kErrNotSupported;
     case 31: return tuning(TUNE_ABLATIONS) == 1 ? launch_geo<V31>(s, p) : kErrNotSupported;
     case 32: return tuning(TUNE_ABLATIONS) == 1 ? launch_geo<V32>(s, p) : kErrNotSupported;
-    case 33: return p.k >= 16 ? launch_geo<V33S>(s, p) : launch_geo<V33>(s, p);
+    case 33: return sdma_fits(p, 16) ? launch_geo<V33S>(s, p) : launch_geo<V33>(s, p);
     case 34: return launch_geo<V34>(s, p);
-    case 35: return p.k >= 32 ? launch_geo<V35S>(s, p) : launch_geo<V35>(s, p);
+    case 35: return sdma_fits(p, 32) ? launch_geo<V35S>(s, p) : launch_geo<V35>(s, p);
     case 36: return launch_geo<V36>(s, p);
-    case 37: return p.k >= 16 ? launch_geo<V37>(s, p) : launch_geo<V25>(s, p);
+    case 37: return sdma_fits(p, 16) ? launch_geo<V37>(s, p) : launch_geo<V25>(s, p);
   }
   return kErrNotSupported;
 }

@@ -360,7 +360,10 @@ int mfma_f64_tile(const Problem &p) {  // 0: 256x128, 1: 128x128
 
 int launch_mfma_f64(hipStream_t s, const Problem &p) {
   if (!mfma_f64_serves(p)) return kErrNotSupported;
-  if (tuning(TUNE_F64_VARIANT) >= 2 || p.k < 16) return mfma_f64_tile(p) == 1 ? launch_d<D1R1>(s, p) : launch_d<D0R1>(s, p);
+  // scalar-base DMA: 32-bit byte offsets inside a tile's rows (256 rows x K x 8 B, 16 k-rows x M x 8 B) and K >= BK
+  const bool sdma_fits = p.k >= 16 && 256ull * (p.a_transposed ? 1ull : p.k) * 8ull < (1ull << 32) &&
+                         16ull * (p.m > p.n ? p.m : p.n) * 8ull < (1ull << 32);
+  if (tuning(TUNE_F64_VARIANT) >= 2 || !sdma_fits) return mfma_f64_tile(p) == 1 ? launch_d<D1R1>(s, p) : launch_d<D0R1>(s, p);
   return mfma_f64_tile(p) == 1 ? launch_d<D1>(s, p) : launch_d<D0>(s, p);
 }
 

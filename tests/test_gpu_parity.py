@@ -481,3 +481,19 @@ def test_f32_baseline_c5a_shape_on_one_gpu_large_offsets():
     row0, cnt = row_slab(n, 8, 3)
     slab = g.matmul(a[row0:row0 + cnt].contiguous(), b)
     assert torch.equal(slab, c[row0:row0 + cnt])
+
+
+def test_f32_and_f64_rows_longer_than_the_scalar_base_dma_reach():
+    """The default kernels address a tile's rows with 32-bit byte offsets from a 64-bit base (256 rows x K x 4 B must
+    stay below 4 GiB); a matrix with longer rows must fall back to the vector-address kernels, not wrap around."""
+    rng = np.random.default_rng(3)
+    k = (1 << 22) + 16                                   # 256 * k * 4 B just above 4 GiB
+    a = rng.uniform(1, 2, size=(8, k)).astype(np.float32)
+    b = rng.uniform(1, 2, size=(k, 4)).astype(np.float32)
+    c, _ = g.matmul_capi(a, b)
+    exact = a.astype(np.float64) @ b.astype(np.float64)
+    assert np.max(np.abs(c - exact) / exact) < 1e-5
+    kd = (1 << 21) + 16                                  # 256 * k * 8 B just above 4 GiB
+    ad, bd = a[:, :kd].astype(np.float64), b[:kd].astype(np.float64)
+    cd, _ = g.matmul_capi(ad, bd, "double")
+    assert np.max(np.abs(cd - ad @ bd) / (ad @ bd)) < 1e-12
