@@ -732,11 +732,16 @@ static int launch_h(hipStream_t s, const Problem &p) {
   return (int)hipGetLastError();
 }
 
+// The DMA addresses a tile's rows with 32-bit byte offsets from a uniform 64-bit base: 256 rows x K x 2 B, and 64 k-rows
+// x M (or N, K x N layout) x 2 B, must stay below 4 GiB; longer rows are served by the round-1 kernel.
+static bool pp_reach(const Problem &p) {
+  return 256ull * (p.a_transposed ? 1ull : p.k) * 2ull < (1ull << 32) && 64ull * (p.m > p.n ? p.m : p.n) * 2ull < (1ull << 32);
+}
 bool mfma_f16_pp_serves(const Problem &p) {
-  return !p.a_transposed && p.k % 32 == 0 && p.k >= 128 && p.m % 8 == 0 && p.m >= 8 && p.n >= 1;
+  return !p.a_transposed && p.k % 32 == 0 && p.k >= 128 && p.m % 8 == 0 && p.m >= 8 && p.n >= 1 && pp_reach(p);
 }
 bool mfma_f16_pp_at_serves(const Problem &p) {
-  return p.a_transposed && p.k % 32 == 0 && p.k >= 128 && p.m % 8 == 0 && p.m >= 8 && p.n % 8 == 0 && p.n >= 8;
+  return p.a_transposed && p.k % 32 == 0 && p.k >= 128 && p.m % 8 == 0 && p.m >= 8 && p.n % 8 == 0 && p.n >= 8 && pp_reach(p);
 }
 
 template <int VAR, bool AT = false>

@@ -596,12 +596,16 @@ bool mfma_i8_serves(const Problem &p) {
   return !p.a_transposed || (p.n >= 16 && p.n % 16 == 0);
 }
 
+// 32-bit byte offsets inside a tile's rows (see mm_mfma_f16.hip): 256 rows x K B and 128 k-rows x max(M, N) B below 4 GiB
+static bool pp_reach(const Problem &p) {
+  return 256ull * (p.a_transposed ? 1ull : p.k) < (1ull << 32) && 128ull * (p.m > p.n ? p.m : p.n) < (1ull << 32);
+}
 bool mfma_i8_pp_serves(const Problem &p) {
-  return !p.a_transposed && p.k % 64 == 0 && p.k >= 256 && p.m % 16 == 0 && p.m >= 16 && p.n >= 1;
+  return !p.a_transposed && p.k % 64 == 0 && p.k >= 256 && p.m % 16 == 0 && p.m >= 16 && p.n >= 1 && pp_reach(p);
 }
 
 bool mfma_i8_pp_at_serves(const Problem &p) {
-  return p.a_transposed && p.k % 64 == 0 && p.k >= 256 && p.m % 16 == 0 && p.m >= 16 && p.n % 16 == 0 && p.n >= 16;
+  return p.a_transposed && p.k % 64 == 0 && p.k >= 256 && p.m % 16 == 0 && p.m >= 16 && p.n % 16 == 0 && p.n >= 16 && pp_reach(p);
 }
 
 template <int VAR, bool AT = false>

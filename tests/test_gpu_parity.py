@@ -497,3 +497,23 @@ def test_f32_and_f64_rows_longer_than_the_scalar_base_dma_reach():
     ad, bd = a[:, :kd].astype(np.float64), b[:kd].astype(np.float64)
     cd, _ = g.matmul_capi(ad, bd, "double")
     assert np.max(np.abs(cd - ad @ bd) / (ad @ bd)) < 1e-12
+
+
+def test_f16_and_i8_rows_longer_than_the_dma_reach():
+    """Same reach rule for the half / int8 ping-pong kernels (256 rows x K x element size < 4 GiB): longer rows run the
+    round-1 kernels -- same contract, same bits for int8."""
+    rng = np.random.default_rng(4)
+    k = (1 << 23) + 64                                   # half: 256 * k * 2 B just above 4 GiB
+    a = rng.uniform(0.5, 1.0, size=(8, k)).astype(np.float16)
+    b = (rng.uniform(0.5, 1.0, size=(k, 8)) * 2.0 ** -12).astype(np.float16)
+    c, _ = g.matmul_capi(a, b, "half")
+    exact = a.astype(np.float64) @ b.astype(np.float64)
+    assert np.max(np.abs(c.astype(np.float64) - exact) / exact) < 2.0 ** -10
+    k8 = (1 << 24) + 128                                 # int8: 256 * k B just above 4 GiB
+    a8 = rng.integers(0, 256, size=(4, k8), dtype=np.uint8)
+    b8 = rng.integers(0, 256, size=(k8, 16), dtype=np.uint8)
+    c8, _ = g.matmul_capi(a8, b8, "uint8_t")
+    acc = np.zeros((4, 16), np.uint32)
+    for i in range(0, k8, 1 << 20):                      # chunked exact reference: sums wrap mod 2^32, then mod 2^8
+        acc += (a8[:, i:i + (1 << 20)].astype(np.uint32) @ b8[i:i + (1 << 20)].astype(np.uint32))
+    assert np.array_equal(c8, acc.astype(np.uint8))
