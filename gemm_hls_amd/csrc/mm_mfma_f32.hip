@@ -828,6 +828,7 @@ using V8S = Geo<2, 4, 2, 16, 2, false, 1, 256, false, false, 9>; // V8 with the 
 using V36 = V8;                                                   // variant 36 pins the builtin (vector-address) DMA form of V8
 using V37 = Geo<2, 4, 2, 16, 2, false, 1, 0, false, false, 9>;    // V25 (no flush) with scalar-base DMA
 using V33S = Geo<2, 2, 2, 16, 2, false, 1, 256, false, false, 9>; // V33 with scalar-base DMA: what variant 33 runs for K >= 16
+using V34S = Geo<2, 2, 2, 16, 3, false, 1, 256, false, false, 9>; // V33S with a ring of 3 (72 KiB LDS per workgroup)
 using V35S = Geo<1, 4, 1, 32, 2, false, 1, 128, false, false, 9>; // V35 with scalar-base DMA: what variant 35 runs for K >= 32
 
 }  // namespace
@@ -976,7 +977,7 @@ int launch_mfma_f32(hipStream_t s, const Problem &p, int variant) {
     case 31: return tuning(TUNE_ABLATIONS) == 1 ? launch_geo<V31>(s, p) : kErrNotSupported;
     case 32: return tuning(TUNE_ABLATIONS) == 1 ? launch_geo<V32>(s, p) : kErrNotSupported;
     case 33: return sdma_fits(p, 16) ? launch_geo<V33S>(s, p) : launch_geo<V33>(s, p);
-    case 34: return launch_geo<V34>(s, p);
+    case 34: return sdma_fits(p, 16) ? launch_geo<V34S>(s, p) : launch_geo<V34>(s, p);
     case 35: return sdma_fits(p, 32) ? launch_geo<V35S>(s, p) : launch_geo<V35>(s, p);
     case 36: return launch_geo<V36>(s, p);
     case 37: return sdma_fits(p, 16) ? launch_geo<V37>(s, p) : launch_geo<V25>(s, p);
