@@ -217,6 +217,20 @@ def extra_workloads(g, torch, dev, local_rank, steps=5):
     return out
 
 
+def self_launch(gpus):
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    sys.stderr.write("[bench] --gpus %d without a launcher: re-running as `%s`\n" % (gpus, " ".join(cmd[1:])))
+    sys.stderr.flush()
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -243,9 +257,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("for --gpus > 1 launch with: python -m torch.distributed.run --nnodes=1 "
-                         f"--nproc-per-node {args.gpus} --master-addr 127.0.0.1 --master-port P bench.py --gpus {args.gpus} ...")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # launched plainly (`python bench.py --gpus G ...`): become the launcher -- one rank per GPU under
+        # torch.distributed.run on a free local port -- and hand its exit status back.  Under a launcher
+        # (WORLD_SIZE set) this branch is never taken.
+        return self_launch(args.gpus)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
     # MM_BENCH_DEVICE_MOD / MM_BENCH_BACKEND exist only so that the N>1 control flow can be smoke-tested
@@ -277,12 +293,29 @@ def main():
         if world > 1:
             dist.barrier()
 
+    ctl_dev = dev if backend == "nccl" else "cpu"
+
     def max_over_ranks(x):
         if world == 1:
             return x
-        t = torch.tensor([x], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        t = torch.tensor([x], dtype=torch.float64, device=ctl_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
+
+    def rows_of_every_rank(rows):
+        """What every rank actually owns, as the formed communicator reports it (one slot per rank, summed)."""
+        if world == 1:
+            return [rows]
+        t = torch.zeros(world, dtype=torch.float64, device=ctl_dev)
+        t[rank] = rows
+        dist.all_reduce(t)
+        return [int(x) for x in t.tolist()]
+
+    ranks_seen = 1
+    if world > 1:
+        one = torch.ones(1, dtype=torch.float64, device=ctl_dev)
+        dist.all_reduce(one)                      # every rank of the communicator contributes 1
+        ranks_seen = int(one.item())
 
     from gemm_hls_amd.partition import row_slab
     k = m = args.size
@@ -297,7 +330,7 @@ def main():
         elapsed = max_over_ranks(elapsed)
         a = b = c = None
         torch.cuda.empty_cache()
-        return rows, elapsed, launch_ms
+        return rows, elapsed, launch_ms, rows_of_every_rank(rows)
 
     if world == 1:
         scaling = args.scaling
@@ -308,11 +341,11 @@ def main():
     else:
         scaling = "weak"
         n_total = args.size * world
-    rows, elapsed, launch_ms = run_job(n_total, 1000)
+    rows, elapsed, launch_ms, rows_all = run_job(n_total, 1000)
 
     weak = None
     if world > 1 and scaling == "strong" and not args.no_extra:
-        w_rows, w_elapsed, w_launch = run_job(args.size * world, 5000)
+        w_rows, w_elapsed, w_launch, _ = run_job(args.size * world, 5000)
         weak = (w_rows, w_elapsed, w_launch)
 
     if rank == 0:
@@ -350,7 +383,10 @@ def main():
             "pct_of_mfma_peak": round(100.0 * value / 1e3 / (peak * world), 2),
             "config": {"workload": what,
                        "kernel": g.kernel_name(g.make_config(dtype, map_op, reduce_op, PATHS.get(args.workload, 0)), rows, k, m),
-                       "rows_total": n_total, "rows_per_gpu": rows},
+                       "rows_total": n_total, "rows_per_gpu": rows_all if world > 1 else rows},
+            # the data path has no collective; this is the barrier / max-over-ranks plane only
+            "control_plane": {"backend": ("rccl (torch.distributed 'nccl')" if backend == "nccl" else backend) if world > 1 else "none",
+                              "ranks_seen": ranks_seen, "devices_visible": torch.cuda.device_count()},
             "roofline": rl,
         }
         if weak is not None:
@@ -370,4 +406,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

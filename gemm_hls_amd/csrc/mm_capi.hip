@@ -333,7 +333,9 @@ int mm_gemm_multi_device(int device_count, const mm_config_t *cfg, const void *a
   if (cfg->layout_a == MM_A_TRANSPOSED)
     return fail(MM_ERR_UNSUPPORTED, "row split of a K x N (transposed) A is not contiguous; use one device");
   const size_t es = mm_dtype_size(cfg->dtype);
-  const unsigned slab = (n + device_count - 1) / device_count;  // rows per device
+  // rows per device: ceil(n / G) rounded up to a whole 128-row macro-tile (the same arithmetic as
+  // gemm_hls_amd/partition.py), so only the last busy device owns a ragged tile row
+  const unsigned slab = (unsigned)std::min<size_t>(n, (((size_t)n + device_count - 1) / device_count + 127) / 128 * 128);
   struct Dev { void *a = nullptr, *b = nullptr, *c = nullptr; unsigned row0 = 0, rows = 0; hipStream_t s = nullptr; };
   std::vector<Dev> devs(device_count);
   auto cleanup = [&]() {

@@ -63,3 +63,40 @@ def test_strong_split_of_the_baseline_job_is_tile_aligned_and_balanced():
         slabs = [row_slab(b.C5A_ROWS, world, r) for r in range(world)]
         assert sum(rows for _, rows in slabs) == b.C5A_ROWS
         assert all(rows == b.C5A_ROWS // world and row0 % 256 == 0 for row0, rows in slabs)
+
+
+def test_plain_launch_with_more_than_one_gpu_becomes_its_own_launcher(monkeypatch):
+    """`python bench.py --gpus 8` outside torch.distributed.run must not stop with a usage message: it
+    re-runs itself under the launcher (one rank per GPU, 127.0.0.1, a free port) and returns its status."""
+    import subprocess
+    import sys
+    b = _bench()
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 7
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "20", "--warmup", "5"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    assert b.main() == 7
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "8" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert 1024 < int(cmd[cmd.index("--master-port") + 1]) < 65536
+    assert cmd[-7:] == [os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "20", "--warmup", "5"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_plain_launch_reaches_the_ranks_without_a_gpu():
+    """End to end on this CPU box: the self-launched ranks start and each one stops at the product's
+    `needs an MI355X` (there is no CPU path) -- not at a launcher usage message."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU box: covered by tests/test_gpu_capi.py")
+    assert r.returncode != 0 and "needs an MI355X" in r.stderr and "torch.distributed.run" in r.stderr

@@ -246,6 +246,24 @@ def test_bench_two_ranks_on_one_device_smoke(scaling):
     assert abs(out["value"] - gops) / out["value"] < 1e-3
 
 
+def test_bench_gpus_2_launched_plainly_spawns_its_own_ranks():
+    """`python bench.py --gpus 2 ...` with NO launcher around it (the shape of the driver's recorded N = 1
+    command): bench.py must start its two ranks itself and print one line that says what the control plane saw."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(MM_BENCH_DEVICE_MOD="1", MM_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--size", "2048", "--total-rows", "6000", "--no-extra"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["config"]["rows_total"] == 6000
+    assert out["control_plane"]["ranks_seen"] == 2 and out["control_plane"]["backend"] == "gloo"
+    # tile-aligned slabs: ceil(6000 / 2) = 3000 -> 3072 rows on rank 0, the ragged rest on rank 1
+    assert out["config"]["rows_per_gpu"] == [3072, 2928]
+
+
 def test_race_screen_of_the_hand_synchronised_kernels():
     """tools/soak.py: every DMA-ring kernel repeated under an uneven background load gives the same bits
     every time and equals an independently scheduled kernel of the same arithmetic (a few seconds)."""

@@ -17,7 +17,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 from gemm_hls_amd.partition import row_slab  # noqa: E402
 
 
-@pytest.mark.parametrize("n,world", [(16384, 8), (65536, 8), (513, 2), (5, 8), (1, 4), (256, 3)])
+@pytest.mark.parametrize("n,world", [(16384, 8), (65536, 8), (513, 2), (5, 8), (1, 4), (256, 3), (6000, 2), (1000, 8), (20000, 3)])
 def test_row_slabs_tile_the_rows(n, world):
     covered = []
     for r in range(world):
@@ -25,7 +25,10 @@ def test_row_slabs_tile_the_rows(n, world):
         assert 0 <= rows and row0 + rows <= n
         covered.extend(range(row0, row0 + rows))
     assert covered == list(range(n))
-    assert max(row_slab(n, world, r)[1] for r in range(world)) == -(-n // world)
+    # slabs are ceil(N/G) rounded up to whole 128-row macro-tiles: every slab start is tile-aligned
+    slab = min(n, -(-(-(-n // world)) // 128) * 128)
+    assert max(row_slab(n, world, r)[1] for r in range(world)) == slab
+    assert all(row_slab(n, world, r)[0] % 128 == 0 or row_slab(n, world, r)[1] == 0 for r in range(world))
 
 
 def _free_port():
