@@ -40,7 +40,13 @@ typedef enum {
 
 /* == the reference's MM_MAP_OP / MM_REDUCE_OP, i.e. hlslib::op::<Name><Data_t>
  * (CMakeLists.txt:33-34, include/Config.h.in:34-35; applied at kernel/Compute.cpp:129,133 and
- * include/Utility.h:29,37).  identity(): Add 0, Multiply 1, And 1, Min max(), Max lowest(). */
+ * include/Utility.h:29,37).  identity(): Add 0, Multiply 1, And 1, Min max(), Max lowest().
+ * hlslib's Operators.h is an absent submodule of the reference tree, so these seeds are NOT pinned by a
+ * reference file: Add / Multiply / And / Min are what any identity of those reductions must be; Max lowest()
+ * is THIS LIBRARY'S CHOICE (the mathematical identity).  The published hlslib is believed to seed Max with
+ * numeric_limits<T>::min() -- for floating types the smallest POSITIVE value -- which differs from lowest()
+ * only when every mapped value of an output is negative; on the reference's own inputs ([1,10]) both give
+ * the same bits, which is all that parity is pinned on. */
 typedef enum {
   MM_OP_ADD = 0,
   MM_OP_MULTIPLY = 1,

@@ -10,7 +10,11 @@
 # -DMM_DYNAMIC_SIZES definition (CMakeLists.txt:96-99,136).  No reference source is copied
 # into the repository; outputs are git-ignored build products.
 #
-# usage: build_ref.sh [DATA_TYPE [MAP_OP [REDUCE_OP [TILE_N TILE_M PAR_N PAR_M]]]]
+# usage: [MM_REF_TRANSPOSED_A=1] build_ref.sh [DATA_TYPE [MAP_OP [REDUCE_OP [TILE_N TILE_M PAR_N PAR_M]]]]
+#   MM_REF_TRANSPOSED_A=1  the reference's -DMM_TRANSPOSED_A build (CMakeLists.txt:30,100-103): `a` is K x N.
+#                          Only its MM_CONVERT_A branch compiles (kernel/Memory.cpp:205-261), which
+#                          Config.h.in:45-48 selects whenever sizeof(Data_t) != the N bus width -- true for every
+#                          type at the default 64-byte bus.
 set -euo pipefail
 REF=${MM_REFERENCE_DIR:-/root/reference}
 HERE=$(cd "$(dirname "$0")" && pwd)
@@ -26,6 +30,8 @@ case "$DT" in
   char|"unsigned char"|uint8_t|int8_t) W=1;; *) echo "unsupported type $DT" >&2; exit 1;;
 esac
 NAME="${DT// /_}_${MAP}_${RED}_${TN}x${TM}_${PN}x${PM}"
+TRANSPOSED=""
+if [ "${MM_REF_TRANSPOSED_A:-0}" = 1 ]; then NAME="${NAME}_transposedA"; TRANSPOSED="-DMM_TRANSPOSED_A"; fi
 OUT="$HERE/_ref/$NAME"
 mkdir -p "$OUT"
 KW=$((W * PM))
@@ -42,7 +48,7 @@ sed -e "s/\${MM_DATA_WIDTH_\${MM_DATA_TYPE}}/$W/g" \
     -e "s/\${MM_KERNEL_WIDTH_M}/$KW/g" \
     "$REF/include/Config.h.in" > "$OUT/Config.h"
 CXX=${CXX:-g++}
-FLAGS="-std=c++17 -O2 -fPIC -pthread -DMM_DYNAMIC_SIZES -I$OUT -I$REF/include -I$HERE/hlslib_shim"
+FLAGS="-std=c++17 -O2 -fPIC -pthread -DMM_DYNAMIC_SIZES $TRANSPOSED -I$OUT -I$REF/include -I$HERE/hlslib_shim"
 if [ "$DT" = half ]; then FLAGS="$FLAGS -DMM_HALF_PRECISION -I$HERE/hlslib_shim/hlslib/xilinx"; fi   # CMakeLists.txt:110-112; hls_half.h is a Vitis include-path header
 $CXX $FLAGS -shared -o "$OUT/libmmkernel_ref.so" \
     "$REF/kernel/Compute.cpp" "$REF/kernel/Memory.cpp" "$REF/kernel/Top.cpp"

@@ -114,32 +114,44 @@ def draws_int(n):
 
 
 # ---- the reference's own kernel, compiled by oracle/build_ref.sh -----------------------------
-def ref_dir(dtype="float", map_op="Multiply", reduce_op="Add", tiles="256x256_32x8"):
-    return os.path.join(ORACLE_DIR, "_ref", f"{dtype.replace(' ', '_')}_{map_op}_{reduce_op}_{tiles}")
+def ref_dir(dtype="float", map_op="Multiply", reduce_op="Add", tiles="256x256_32x8", transposed_a=False):
+    return os.path.join(ORACLE_DIR, "_ref", f"{dtype.replace(' ', '_')}_{map_op}_{reduce_op}_{tiles}"
+                        + ("_transposedA" if transposed_a else ""))
 
 
-def ref_available(dtype="float", map_op="Multiply", reduce_op="Add"):
-    return os.path.exists(os.path.join(ref_dir(dtype, map_op, reduce_op), "libmmkernel_ref.so"))
+def ref_available(dtype="float", map_op="Multiply", reduce_op="Add", transposed_a=False):
+    return os.path.exists(os.path.join(ref_dir(dtype, map_op, reduce_op, transposed_a=transposed_a), "libmmkernel_ref.so"))
 
 
 _ref_libs = {}
 
 
-def ref_kernel(dtype, map_op, reduce_op, a, b):
+def ref_kernel(dtype, map_op, reduce_op, a, b, transposed_a=False):
     """Call the reference's extern "C" MatrixMultiplicationKernel (kernel/Top.cpp:6) compiled
-    from /root/reference against the hlslib shim: the repo's own CPU simulation path."""
-    key = (dtype, map_op, reduce_op)
+    from /root/reference against the hlslib shim: the repo's own CPU simulation path.
+    transposed_a: the reference's -DMM_TRANSPOSED_A build, `a` is K x N (N a multiple of the bus
+    width in elements: SizeNMemory floors, include/MatrixMultiplication.h:61-64)."""
+    key = (dtype, map_op, reduce_op, bool(transposed_a))
     if key not in _ref_libs:
-        L = ctypes.CDLL(os.path.join(ref_dir(*key), "libmmkernel_ref.so"))
+        L = ctypes.CDLL(os.path.join(ref_dir(dtype, map_op, reduce_op, transposed_a=transposed_a), "libmmkernel_ref.so"))
         L.MatrixMultiplicationKernel.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_uint] * 3
         L.MatrixMultiplicationKernel.restype = None
         _ref_libs[key] = L
-    n, k = a.shape
-    m = b.shape[1]
+    k, m = b.shape
+    n = a.shape[1] if transposed_a else a.shape[0]
+    assert a.shape == ((k, n) if transposed_a else (n, k))
     npdt = NP_DTYPES[dtype]
-    a = np.ascontiguousarray(a, dtype=npdt)
-    b = np.ascontiguousarray(b, dtype=npdt)
+    # The reference's readers index whole outer tiles and rely on WriteC's mask (SURVEY.md H7): on a ragged
+    # last tile ReadA runs up to 255 rows past A (kernel/Memory.cpp:11-20,64), ReadB up to one tile width past B
+    # (:36-44,282).  Back both operands with zero-filled slack so those reads stay inside memory this process
+    # owns (without it the call segfaults now and then, depending on where numpy put the arrays).
+    def backed(x, slack):
+        buf = np.zeros(x.size + slack, dtype=npdt)
+        buf[:x.size] = np.ascontiguousarray(x, dtype=npdt).reshape(-1)
+        return buf
+    a_buf = backed(a, 256 * max(n, k) + 4096)
+    b_buf = backed(b, 256 * max(k, m) + 4096)
     c = np.zeros((n, m), dtype=npdt)
     # stdout of WriteC's per-tile progress line (kernel/Memory.cpp:384-389) is left alone
-    _ref_libs[key].MatrixMultiplicationKernel(_ptr(a), _ptr(b), _ptr(c), n, k, m)
+    _ref_libs[key].MatrixMultiplicationKernel(_ptr(a_buf), _ptr(b_buf), _ptr(c), n, k, m)
     return c

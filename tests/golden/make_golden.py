@@ -4,7 +4,8 @@ the kernel fixtures, /root/reference so that oracle/build_ref.sh can compile the
 own kernel).  The GPU box only reads the fixtures.
 
   rng_golden.json           first 256 draws of the reference's input generator (libstdc++)
-  ref_<cfg>_<N>x<K>x<M>.npz C computed by the REFERENCE'S OWN kernel sources
+  ref_[transposedA_]<cfg>_<N>x<K>x<M>.npz
+                            C computed by the REFERENCE'S OWN kernel sources
                             (kernel/{Compute,Memory,Top}.cpp via oracle/_ref) on the
                             reference's seeded inputs; A and B are not stored (regenerated from
                             the seed by the oracle's generator, whose draws rng_golden.json pins).
@@ -37,24 +38,38 @@ def main():
     subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "-s"], check=True, stdout=subprocess.DEVNULL)
     small = [(37, 32, 48), (1, 16, 16), (300, 64, 272)]
     checks = {}
+    # bus = 64 bytes -> K and M are multiples of 64 / sizeof(Data_t) elements (host/RunHardware.cpp:50-61), and K of the
+    # transpose width as well (test/TestSimulation.cpp:28-33); the CTest shape is CMakeLists.txt:155-159's per width.
     # half: the reference's kernel accumulates in binary16 (Xilinx `half`; oracle/hlslib_shim/.../hls_half.h is
-    # an IEEE binary16 with round-to-nearest-even) -- the semantics RunHardware's hw_emu mode reproduces
-    for dtype, mp, rd in [("float", "Multiply", "Add"), ("int", "Multiply", "Add"), ("float", "Add", "Min"),
-                          ("half", "Multiply", "Add")]:
-        if not _oracle.ref_available(dtype, mp, rd):
-            print("skip (oracle/_ref not built):", dtype, mp, rd)
+    # an IEEE binary16 with round-to-nearest-even) -- the semantics RunHardware's hw_emu mode reproduces.
+    # MM_TRANSPOSED_A builds: `a` is K x N and N must be a multiple of the bus width too (SizeNMemory floors,
+    # include/MatrixMultiplication.h:61-64) -- which is why the reference's own CTest shape (N = 513) FAILS for that
+    # build (observed here: "Mismatch at (0, 0)"); the shapes below keep N % 16 == 0.
+    shapes = {
+        "half": ([(37, 32, 64), (1, 32, 32), (300, 64, 288)], (513, 544, 544)),
+        "double": ([(37, 16, 24), (1, 8, 8), (300, 64, 264)], (513, 520, 520)),
+        "uint8_t": ([(37, 64, 64), (1, 64, 64), (300, 128, 320)], (513, 576, 576)),
+    }
+    transposed_shapes = ([(48, 32, 48), (16, 16, 16), (304, 64, 272)], (528, 528, 528))
+    configs = [("float", "Multiply", "Add", False), ("int", "Multiply", "Add", False), ("float", "Add", "Min", False),
+               ("half", "Multiply", "Add", False), ("double", "Multiply", "Add", False), ("uint8_t", "Multiply", "Add", False),
+               ("float", "Multiply", "Add", True), ("int", "Multiply", "Add", True)]
+    for dtype, mp, rd, ta in configs:
+        if not _oracle.ref_available(dtype, mp, rd, transposed_a=ta):
+            print("skip (oracle/_ref not built):", dtype, mp, rd, "transposedA" if ta else "")
             continue
-        # half: the 64-byte bus is 32 elements, so K and M are multiples of 32 (host/RunHardware.cpp:50-61)
-        for (n, k, m) in ([(37, 32, 64), (1, 32, 32), (300, 64, 288)] if dtype == "half" else small):
-            a, b = _oracle.fill(dtype, n, k, m)
-            c = _oracle.ref_kernel(dtype, mp, rd, a, b)
-            np.savez_compressed(os.path.join(HERE, f"ref_{dtype}_{mp}_{rd}_{n}x{k}x{m}.npz"), c=c,
+        cases, ctest = transposed_shapes if ta else shapes.get(dtype, (small, (513, 528, 528)))
+        tag = "transposedA_" if ta else ""
+        for (n, k, m) in cases:
+            a, b = _oracle.fill(dtype, n, k, m, transposed_a=ta)
+            c = _oracle.ref_kernel(dtype, mp, rd, a, b, transposed_a=ta)
+            np.savez_compressed(os.path.join(HERE, f"ref_{tag}{dtype}_{mp}_{rd}_{n}x{k}x{m}.npz"), c=c,
                                 a_sha256=hashlib.sha256(a.tobytes()).hexdigest(),
                                 b_sha256=hashlib.sha256(b.tobytes()).hexdigest())
-        n, k, m = (513, 544, 544) if dtype == "half" else (513, 528, 528)  # CMakeLists.txt:155-159 per bus width
-        a, b = _oracle.fill(dtype, n, k, m)
-        c = _oracle.ref_kernel(dtype, mp, rd, a, b)
-        checks[f"{dtype}_{mp}_{rd}"] = {
+        n, k, m = ctest
+        a, b = _oracle.fill(dtype, n, k, m, transposed_a=ta)
+        c = _oracle.ref_kernel(dtype, mp, rd, a, b, transposed_a=ta)
+        checks[f"{tag}{dtype}_{mp}_{rd}"] = {
             "shape": [n, k, m],
             "a_sha256": hashlib.sha256(a.tobytes()).hexdigest(),
             "b_sha256": hashlib.sha256(b.tobytes()).hexdigest(),

@@ -259,3 +259,24 @@ def test_uint8_32768_bit_exact_against_ordered_kernel_and_naive():
     # the same bytes read as int8_t give the same result bytes (u8 = s8 mod 2^8)
     c_s = g.matmul(a.view(torch.int8), b.view(torch.int8), "int8_t")
     assert torch.equal(c_s.view(torch.uint8), c)
+
+
+# ---- C1: float 1024^3, the reference's own simulation path, LIVE next to the device ---------------------
+def test_c1_float_1024_device_next_to_the_reference_kernel_itself():
+    """BASELINE configs[0]: the reference's MatrixMultiplicationKernel (its kernel/*.cpp compiled against the
+    test-only hlslib shim into oracle/_ref, the same call bench.py's cpu_baseline times, ~7 s on the box's host
+    cores) on the seeded float 1024^3 inputs of test/TestSimulation.cpp:42-55 -- and the device result beside it:
+    hw_emu / MM_PATH_ORDERED must give the reference kernel's bits (same k-ordered unfused chain,
+    kernel/Compute.cpp:108-142), hw / MM_PATH_AUTO must agree within BASELINE's 1e-5."""
+    if not _oracle.ref_available():
+        pytest.skip("oracle/_ref not built in this snapshot (needs /root/reference at build time)")
+    n = k = m = 1024
+    a, b = _oracle.fill("float", n, k, m)
+    c_ref = _oracle.ref_kernel("float", "Multiply", "Add", a, b)
+    c_ord, _ = g.matmul_capi(a, b, path=g.PATH_ORDERED)
+    assert np.array_equal(c_ord, c_ref)
+    c, _ = g.matmul_capi(a, b)
+    bad, first, worst = _oracle.compare("float", c, c_ref, 1e-5)
+    assert bad == 0, (bad, first, worst)
+    # the reference's own acceptance rule for this path (TestSimulation: 1e-3 against ReferenceImplementation)
+    assert _oracle.compare("float", c_ref, _oracle.naive("float", "Multiply", "Add", a, b), 1e-3)[0] == 0

@@ -350,23 +350,27 @@ def test_valu_tile_dma_staged_kernel_equals_synchronous_kernel_and_naive(dtype, 
 def _golden_cases():
     for path in sorted(glob.glob(os.path.join(GOLD, "ref_*_*x*x*.npz"))):
         stem = os.path.basename(path)[4:-4]
-        dtype, mp, rd, shape = stem.rsplit("_", 3)
+        ta = stem.startswith("transposedA_")          # the reference's -DMM_TRANSPOSED_A build: A is K x N
+        dtype, mp, rd, shape = stem[len("transposedA_") if ta else 0:].rsplit("_", 3)
         if (mp, rd) == ("Add", "Min"):
             continue  # reference kernel defect H4 (literal-0 seed); Naive semantics are tested above
-        yield pytest.param(path, dtype, mp, rd, tuple(int(x) for x in shape.split("x")), id=stem)
+        yield pytest.param(path, dtype, mp, rd, tuple(int(x) for x in shape.split("x")), ta, id=stem)
 
 
-@pytest.mark.parametrize("path,dtype,mp,rd,shape", list(_golden_cases()))
-def test_against_reference_kernel_golden_outputs(path, dtype, mp, rd, shape):
-    """C committed from the reference's OWN kernel sources (tests/golden/make_golden.py)."""
+@pytest.mark.parametrize("path,dtype,mp,rd,shape,ta", list(_golden_cases()))
+def test_against_reference_kernel_golden_outputs(path, dtype, mp, rd, shape, ta):
+    """C committed from the reference's OWN kernel sources (tests/golden/make_golden.py): float, int, half,
+    double, uint8_t builds and the MM_TRANSPOSED_A (K x N `a`) builds of float and int."""
     n, k, m = shape
-    a, b = _oracle.fill(dtype, n, k, m)
+    a, b = _oracle.fill(dtype, n, k, m, transposed_a=ta)
     ref = np.load(path)["c"]
-    c_ord, _ = g.matmul_capi(a, b, dtype, mp, rd, path=g.PATH_ORDERED)
+    c_ord, _ = g.matmul_capi(a, b, dtype, mp, rd, path=g.PATH_ORDERED, transposed_a=ta)
     assert np.array_equal(c_ord, ref)  # same k-ordered unfused chain -> bit-identical, floats too
-    c, _ = g.matmul_capi(a, b, dtype, mp, rd)
+    c, _ = g.matmul_capi(a, b, dtype, mp, rd, transposed_a=ta)
     if dtype == "float":
         assert _oracle.compare("float", c, ref, F32_TOL)[0] == 0
+    elif dtype == "double":
+        assert _oracle.compare("double", c, ref, 1e-13)[0] == 0   # fused vs unfused chain of <= 64 positive terms
     elif dtype == "half":
         # AUTO accumulates in f32 and rounds once (include/mm_gemm.h, half contract); the reference's kernel
         # rounds after every one of the K additions: the two differ by at most K half-ulps of the running sum

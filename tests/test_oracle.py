@@ -134,15 +134,17 @@ def test_compare_rule():
 def _golden_cases():
     for path in sorted(glob.glob(os.path.join(GOLD, "ref_*_*x*x*.npz"))):
         stem = os.path.basename(path)[4:-4]
-        dtype, mp, rd, shape = stem.rsplit("_", 3)
-        yield pytest.param(path, dtype, mp, rd, tuple(int(x) for x in shape.split("x")), id=stem)
+        ta = stem.startswith("transposedA_")          # the reference's -DMM_TRANSPOSED_A build: A is K x N
+        dtype, mp, rd, shape = stem[len("transposedA_") if ta else 0:].rsplit("_", 3)
+        yield pytest.param(path, dtype, mp, rd, tuple(int(x) for x in shape.split("x")), ta, id=stem)
 
 
-@pytest.mark.parametrize("path,dtype,mp,rd,shape", list(_golden_cases()))
-def test_oracle_reproduces_reference_kernel_golden(path, dtype, mp, rd, shape):
+@pytest.mark.parametrize("path,dtype,mp,rd,shape,ta", list(_golden_cases()))
+def test_oracle_reproduces_reference_kernel_golden(path, dtype, mp, rd, shape, ta):
     n, k, m = shape
     z = np.load(path)
-    a, b = _oracle.fill(dtype, n, k, m)
+    a, b = _oracle.fill(dtype, n, k, m, transposed_a=ta)
+    assert a.shape == ((k, n) if ta else (n, k))
     assert hashlib.sha256(a.tobytes()).hexdigest() == str(z["a_sha256"])
     assert hashlib.sha256(b.tobytes()).hexdigest() == str(z["b_sha256"])
     c_ref = z["c"]
@@ -155,21 +157,35 @@ def test_oracle_reproduces_reference_kernel_golden(path, dtype, mp, rd, shape):
         want = (a.astype(np.float64)[:, :, None] + b.astype(np.float64)[None]).min(axis=1)
         assert np.array_equal(c, want.astype(np.float32))
         return
-    c = _oracle.naive(dtype, mp, rd, a, b)
+    c = _oracle.naive(dtype, mp, rd, a, b, transposed_a=ta)
     # The HLS kernel accumulates k = 0..K-1 into one accumulator starting from 0, unfused:
-    # the same chain as Naive -> bit-identical, floats included.
+    # the same chain as Naive -> bit-identical, floats and doubles included; uint8_t wraps mod 2^8
+    # in both; with MM_TRANSPOSED_A only the indexing of `a` changes (include/Utility.h:31-35).
     assert np.array_equal(c, c_ref)
+    if ta:  # and the K x N layout is the same product as the row-major one
+        assert np.array_equal(_oracle.naive(dtype, mp, rd, np.ascontiguousarray(a.T), b), c_ref)
+
+
+def test_goldens_cover_every_reference_build_the_oracle_makefile_names():
+    have = {os.path.basename(p)[4:-4].rsplit("_", 1)[0] for p in glob.glob(os.path.join(GOLD, "ref_*_*x*x*.npz"))}
+    assert have >= {"float_Multiply_Add", "float_Add_Min", "int_Multiply_Add", "half_Multiply_Add", "double_Multiply_Add",
+                    "uint8_t_Multiply_Add", "transposedA_float_Multiply_Add", "transposedA_int_Multiply_Add"}
 
 
 def test_oracle_reproduces_reference_ctest_shape_checksum():
     checks = json.load(open(os.path.join(GOLD, "ref_checksums.json")))
-    for cfg in ("float_Multiply_Add", "int_Multiply_Add", "half_Multiply_Add"):
-        dtype, mp, rd = cfg.split("_")
-        n, k, m = checks[cfg]["shape"]
-        a, b = _oracle.fill(dtype, n, k, m)
-        assert hashlib.sha256(a.tobytes()).hexdigest() == checks[cfg]["a_sha256"]
-        c = _oracle.naive(dtype, mp, rd, a, b)
-        assert hashlib.sha256(c.tobytes()).hexdigest() == checks[cfg]["c_sha256"]
+    assert set(checks) >= {"float_Multiply_Add", "int_Multiply_Add", "half_Multiply_Add", "double_Multiply_Add",
+                           "uint8_t_Multiply_Add", "transposedA_float_Multiply_Add", "transposedA_int_Multiply_Add"}
+    for cfg, chk in checks.items():
+        ta = cfg.startswith("transposedA_")
+        dtype, mp, rd = cfg[len("transposedA_") if ta else 0:].rsplit("_", 2)
+        if (mp, rd) == ("Add", "Min"):
+            continue   # reference defect H4, see above
+        n, k, m = chk["shape"]
+        a, b = _oracle.fill(dtype, n, k, m, transposed_a=ta)
+        assert hashlib.sha256(a.tobytes()).hexdigest() == chk["a_sha256"]
+        c = _oracle.naive(dtype, mp, rd, a, b, transposed_a=ta)
+        assert hashlib.sha256(c.tobytes()).hexdigest() == chk["c_sha256"], cfg
 
 
 @pytest.mark.skipif(not _oracle.ref_available(), reason="oracle/_ref not built (needs /root/reference)")
@@ -181,3 +197,15 @@ def test_reference_kernel_live_ragged_tiles():
     assert np.array_equal(_oracle.naive("float", "Multiply", "Add", a, b), c_ref)
     bad, _, worst = _oracle.compare("float", c_ref, (a.astype(np.float64) @ b.astype(np.float64)).astype(np.float32), 1e-5)
     assert bad == 0 and worst < 1e-5
+
+
+@pytest.mark.parametrize("dtype,ta,shape", [("double", False, (257, 64, 264)), ("uint8_t", False, (257, 128, 320)),
+                                            ("float", True, (272, 64, 272)), ("int", True, (16, 32, 272))])
+def test_reference_kernel_live_other_builds(dtype, ta, shape):
+    """The double, uint8_t and MM_TRANSPOSED_A builds of the reference's kernel, run live next to the restatement."""
+    if not _oracle.ref_available(dtype, "Multiply", "Add", transposed_a=ta):
+        pytest.skip("oracle/_ref not built (needs /root/reference)")
+    n, k, m = shape
+    a, b = _oracle.fill(dtype, n, k, m, transposed_a=ta)
+    c_ref = _oracle.ref_kernel(dtype, "Multiply", "Add", a, b, transposed_a=ta)
+    assert np.array_equal(_oracle.naive(dtype, "Multiply", "Add", a, b, transposed_a=ta), c_ref)
