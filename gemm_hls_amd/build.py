@@ -72,7 +72,7 @@ def build(verbose=True):
             jobs.append([HIPCC] + COMMON + EXTRA.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj])
     with concurrent.futures.ThreadPoolExecutor(max_workers=os.cpu_count() or 4) as ex:
         list(ex.map(run, jobs))
-    if jobs or not os.path.exists(LIB):
+    if jobs or newer(LIB, objs):   # also after an object was rebuilt by hand
         run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs)
     if verbose:
         print(f"built {LIB} ({len(jobs)} objects recompiled)")

@@ -713,6 +713,181 @@ __global__ __launch_bounds__(GeoPP2::THREADS) void mfma_f16_pp2_kernel(const _Fl
     }
   }
 }
+
+// -------------------------------------------------------------------------------------------------
+// Ping-pong kernel on v_mfma_f32_16x16x32_f16 ("pp2s", round 3).  Same tile, LDS rings, DMA and segment
+// protocol as pp2; what changes is the matrix instruction: 16 x 16 outputs x 32 k (4 accumulator
+// registers, 16 cycles) instead of 32 x 32 x 16 (16 registers, 32 cycles).  Both run at the same flop rate,
+// but on random [1,10) operands the register-only loop of the 16x16x32 form holds 1.98 GHz = 2.06 PF where
+// the 32x32x16 form holds 1.68 GHz = 1.76 PF (tools/probes/probe_mfma_power.hip,
+// profiles/r03b_probe_mfma_power_by_shape_and_operand_order.txt): the kernel is power-limited, so the
+// cheaper instruction is clock for everything else.  A wavefront's 128 x 64 block is 8 x 4 accumulators;
+// per 32-deep slab it reads 8 A operands (ds_read_b128: row l&15, k = 8*(l>>4)..+7 -- one slab = one MFMA k)
+// and 4 B operands (two ds_read_b64_tr_b16 each: lane group l>>4 gathers k = 8*(l>>4)..+7 of 16 columns):
+// the same 16 LDS instructions and bytes as before, now for 32 MFMAs.
+//   A image: unchanged ([256 rows][64 k] double slabs, chunk ^ (row>>1)&7): the four 16-lane service groups
+//     of a ds_read_b128 still cover 16 distinct 16-B slots (tests/test_layouts.py).
+//   B image [32 k][256 cols]: the two 16-lane groups of a half-wave now differ in k by 8 instead of in
+//     column by 16, so the chunk index is XORed with ((k>>3)&1)<<1 on top of (k&3)<<2: the 8 k-rows a
+//     half-wave touches fall into 8 different 32-byte octants of the 256-byte bank row.
+// Accumulation order per output element: k ascending in steps of 32, inside an MFMA the hardware's order;
+// results are within the same 1-ulp-of-binary16 bound as the 32x32x16 kernels (not bit-identical to them).
+template <int VAR>  // bit 1: lock-step ablation
+__global__ __launch_bounds__(GeoPP2::THREADS) void mfma_f16_pp2s_kernel(const _Float16 *__restrict__ A,
+                                                                          const _Float16 *__restrict__ B,
+                                                                          _Float16 *__restrict__ C, unsigned N, unsigned K,
+                                                                          unsigned M, unsigned tiles_n, unsigned tiles_m,
+                                                                          unsigned kBand) {
+  using G = GeoPP2;
+  constexpr int RB = 8, NB = 4;  // 16-row / 16-column blocks of a wavefront's 128 x 64 part
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const unsigned lane = threadIdx.x & 63u;
+  const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const unsigned group = wave >> 2, wq = wave & 3u;
+  const unsigned wm = wq >> 1, wn = (wq & 1u) * 2 + group;
+  const unsigned l15 = lane & 15u, g = lane >> 4;
+
+  const unsigned lin = xcd_remap(blockIdx.x, tiles_n * tiles_m);
+  const unsigned band = lin / (kBand * tiles_m), within = lin % (kBand * tiles_m);
+  const unsigned rows_in_band = min(kBand, tiles_n - band * kBand);
+  const unsigned row0 = (band * kBand + within % rows_in_band) * G::BM, col0 = (within / rows_in_band) * G::BN;
+
+  unsigned voff_a[4], voff_b[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const unsigned row = (wave + 8 * i) * 8 + lane / 8, pc = lane % 8;
+    voff_a[i] = (min(row0 + row, N - 1) - row0) * K * 2 + (pc ^ ((row >> 1) & 7u)) * 16;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const unsigned kr = (wave + 8 * i) * 2 + lane / 32, pb = lane % 32;
+    const unsigned lc = pb ^ ((kr & 3u) << 2) ^ (((kr >> 3) & 1u) << 1);
+    voff_b[i] = kr * M * 2 + (min(col0 + lc * 8, M - 8) - col0) * 2;
+  }
+  const char *a_base = (const char *)A + (size_t)row0 * K * 2;
+  const char *b_base = (const char *)B + (size_t)col0 * 2;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
+  const unsigned U = K / G::BK, UD = U / 2;
+#define MM_PP2_ISSUE(V0, V1, SB, L0, L1)                                                                   \
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3"       \
+               "\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0" \
+               : "=&s"(keep)                                                                               \
+               : "v"(V0), "v"(V1), "s"(SB), "s"(L0), "s"(L1)                                               \
+               : "memory")
+  auto issue_a = [&](unsigned ds, unsigned abuf, int h) {
+    const char *ap = a_base + (size_t)min(ds, UD - 1) * 128;
+    const unsigned la0 = lds0 + abuf * G::A2_BYTES + (wave + 16 * h) * 1024, la1 = la0 + 8 * 1024;
+    const unsigned v0 = h ? voff_a[2] : voff_a[0], v1 = h ? voff_a[3] : voff_a[1];
+    unsigned keep;
+    MM_PP2_ISSUE(v0, v1, ap, la0, la1);
+  };
+  auto issue_b = [&](unsigned slab, unsigned bbuf) {
+    const char *bp = b_base + (size_t)min(slab, U - 1) * G::BK * M * 2;
+    const unsigned lb0 = lds0 + G::B_REGION + bbuf * G::B_BYTES + wave * 1024, lb1 = lb0 + 8 * 1024;
+    unsigned keep;
+    MM_PP2_ISSUE(voff_b[0], voff_b[1], bp, lb0, lb1);
+  };
+#undef MM_PP2_ISSUE
+
+  // A: row = wm*128 + rb*16 + l15, logical chunk = 4*H + g (H = slab parity inside the double slab), physical = logical ^ (row>>1)&7
+  const unsigned a_row_byte = (wm * 128 + l15) * 128;
+  const unsigned a_off[2] = {a_row_byte + (g ^ (l15 >> 1)) * 16, a_row_byte + ((4u + g) ^ (l15 >> 1)) * 16};
+  // B (transpose read): k = 8*g + 4*h2 + r, r = l15>>2; 8-byte piece l15&3 of the block's 32 B (16 columns)
+  const unsigned r = l15 >> 2, piece = l15 & 3u;
+  unsigned b_off[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    const unsigned logical = wn * 8 + nb * 2 + (piece >> 1);
+    b_off[nb] = G::B_REGION + (8 * g + r) * G::BROW + (logical ^ (r << 2) ^ ((g & 1u) << 1)) * 16 + (piece & 1u) * 8;
+  }
+
+  using f32x4 = __attribute__((ext_vector_type(4))) float;
+  f32x4 acc[RB][NB];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) acc[rb][nb] = (f32x4)0.0f;
+
+  auto sync = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto phase = [&](auto bufc, unsigned u, unsigned abuf) {
+    constexpr int BUF = decltype(bufc)::value;
+    constexpr int H = BUF & 1;
+    const char *abase = smem + abuf * G::A2_BYTES;
+    const char *bbase = smem + BUF * G::B_BYTES;
+    h8 af[RB], bf[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      const char *p = bbase + b_off[nb];
+      const s4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s4 __attribute__((address_space(3))) *)(lptr_t)p);
+      const s4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s4 __attribute__((address_space(3))) *)(lptr_t)(p + 4 * G::BROW));
+      bf[nb] = join(v0, v1);
+    }
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) af[rb] = *(const h8 *)(abase + a_off[H] + rb * 16 * 128);
+    const unsigned abuf_fill = abuf >= 1 ? abuf - 1 : 2;
+    issue_a(u / 2 + 2, abuf_fill, H);
+    issue_b(u + 3, (BUF + 3) & 3);
+    asm volatile("s_waitcnt vmcnt(8)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+    sync();
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+        acc[rb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[rb], bf[nb], acc[rb][nb], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    sync();
+  };
+
+  issue_a(0, 0, 0);
+  issue_a(0, 0, 1);
+  issue_b(0, 0);
+  issue_a(1, 1, 0);
+  issue_b(1, 1);
+  issue_a(1, 1, 1);
+  issue_b(2, 2);
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  sync();
+  const bool shifted = !(VAR & 2) && group == 1;
+  if (shifted) sync();
+  unsigned ab = 0;
+  for (unsigned u = 0; u < U; u += 4) {
+    const unsigned ab1 = ab == 2 ? 0 : ab + 1;
+    phase(std::integral_constant<int, 0>{}, u, ab);
+    phase(std::integral_constant<int, 1>{}, u + 1, ab);
+    if (u + 2 < U) {
+      phase(std::integral_constant<int, 2>{}, u + 2, ab1);
+      phase(std::integral_constant<int, 3>{}, u + 3, ab1);
+    }
+    ab = ab1 == 2 ? 0 : ab1 + 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (!shifted && !(VAR & 2)) sync();
+  sync();
+
+  {  // epilogue: C/D of the 16x16 form: column l15, rows 4*g + i
+    char *slice = smem + wave * (128 * 128);
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          *(_Float16 *)(slice + (rb * 16 + 4 * g + i) * 128 + (nb * 16 + l15) * 2) = (_Float16)acc[rb][nb][i];
+    using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+#pragma unroll
+    for (int it = 0; it < 128 * 8 / 64; ++it) {
+      const unsigned c = it * 64 + lane, row = c / 8, ch = c % 8;
+      const u32x4 v = *(const u32x4 *)(slice + row * 128 + ch * 16);
+      const unsigned grow = row0 + wm * 128 + row, gcol = col0 + wn * 64 + ch * 8;
+      if (grow < N && gcol < M) *(u32x4 *)(C + (size_t)grow * M + gcol) = v;
+    }
+  }
+}
 #undef MM_DMA_PIECE
 
 }  // namespace
@@ -768,6 +943,17 @@ static int launch_pp2(hipStream_t s, const Problem &p) {
   return (int)hipGetLastError();
 }
 
+template <int VAR>
+static int launch_pp2s(hipStream_t s, const Problem &p) {
+  using G = GeoPP2;
+  const unsigned tiles_n = (p.n + G::BM - 1) / G::BM, tiles_m = (p.m + G::BN - 1) / G::BN;
+  static unsigned long long configured = 0;
+  if (int e = ensure_dynamic_lds((const void *)mfma_f16_pp2s_kernel<VAR>, G::LDS_BYTES, configured)) return e;
+  hipLaunchKernelGGL((mfma_f16_pp2s_kernel<VAR>), dim3(tiles_n * tiles_m), dim3(G::THREADS), G::LDS_BYTES, s,
+                     (const _Float16 *)p.a, (const _Float16 *)p.b, (_Float16 *)p.c, p.n, p.k, p.m, tiles_n, tiles_m, band_rows());
+  return (int)hipGetLastError();
+}
+
 int mfma_f16_tile(const Problem &p) {  // 0: 256x256, 4: 128x256
   static const TileCandidate cands[] = {{0, 256, 256, 1, 1.00}, {4, 128, 256, 1, 0.80}};
   return p.a_transposed ? 0 : pick_tile(cands, 2, p.n, p.m);
@@ -780,6 +966,8 @@ int launch_mfma_f16(hipStream_t s, const Problem &p) {
     if (v != 0 && mfma_f16_pp_at_serves(p)) return launch_pp<1, true>(s, p);
     return launch_h<GeoH, true>(s, p);
   }
+  if (v == 200 && mfma_f16_pp2_serves(p)) return launch_pp2s<0>(s, p);   // 16x16x32 matrix instruction
+  if (v == 202 && mfma_f16_pp2_serves(p)) return launch_pp2s<2>(s, p);   // its lock-step ablation
   if (v >= 100 && v < 200 && mfma_f16_pp2_serves(p)) {  // 100 + VAR of the full-line-A ping-pong kernel
     switch (v - 100) {
       case 0: return launch_pp2<0>(s, p);

@@ -160,7 +160,7 @@ def test_f16_mfma_wide_accumulate_contract(shape):
     assert rel.max() <= 2.0 ** -11 * 1.01      # half an ulp of binary16 relative to the exact value (+f32 noise)
 
 
-@pytest.mark.parametrize("variant", [10, 11, 12, 13, 14, 15, 19, 23, 100, 102, 0, 1, 4])
+@pytest.mark.parametrize("variant", [10, 11, 12, 13, 14, 15, 19, 23, 100, 102, 200, 202, 0, 1, 4])
 @pytest.mark.parametrize("shape", [(513, 544, 528), (300, 128, 272), (257, 1056, 520), (1024, 4096, 1024), (129, 160, 264),
                                    (770, 2048, 1288), (300, 256, 272), (513, 576, 528), (260, 320, 264)],
                          ids=lambda s: "x".join(map(str, s)))
