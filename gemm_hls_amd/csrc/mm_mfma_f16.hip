@@ -888,6 +888,199 @@ __global__ __launch_bounds__(GeoPP2::THREADS) void mfma_f16_pp2s_kernel(const _F
     }
   }
 }
+
+// -------------------------------------------------------------------------------------------------
+// 384 x 256 tile on the 16x16x32 instruction ("pp3", round 3).  The power breakdown of the 256 x 256 kernels says
+// the global -> LDS path is the largest consumer beside the matrix cores and its bytes per flop are fixed by the
+// tile: (BM + BN) / (BM * BN).  384 x 256 moves 16.7 % fewer bytes per flop through L2 -> LDS and, for the same
+// 4 x 8 arrangement of an XCD's 32 resident tiles, 22 % fewer through the fabric.  It fits because the 16-row
+// granularity of the 16x16x32 form allows a 96 x 128 wavefront part (6 x 8 accumulators = 192 registers):
+//   8 wavefronts as 4 x 2; SIMD partners (w, w + 4) side by side in N; ping-pong protocol as above;
+//   ring of 4 stages of [A 384 rows x 32 k (64-byte rows)] + [B 32 k x 256 cols] = 4 x 40 KiB = all of the LDS
+//   (three A double slabs of 128-byte rows would need 144 KiB: the full-line A requests of pp2 do not fit);
+//   a wavefront issues 5 DMA pieces per segment (3 of A, 2 of B) against 48 MFMAs; two slabs in flight, counted vmcnt(5).
+//   A image: 64-byte rows, chunk index ^ (-(row>>2))&3 -- with the 16x16 operand (row l&15, chunk l>>4) each
+//   ds_read_b128 service group covers 16 distinct slots (tests/test_layouts.py); B image as pp2s.
+// Requirements: K % 32 == 0, K >= 128, M % 8 == 0, row-major A.
+struct GeoPP3 {
+  static constexpr int BM = 384, BN = 256, BK = 32, NS = 4, THREADS = 512;
+  static constexpr int RB = 6, NB = 8;  // 96 x 128 per wavefront
+  static constexpr int A_BYTES = BM * BK * 2, B_BYTES = BK * BN * 2, STAGE_BYTES = A_BYTES + B_BYTES;  // 24 + 16 KiB
+  static constexpr int LDS_BYTES = NS * STAGE_BYTES;  // 163840
+  static constexpr int BROW = BN * 2;
+};
+
+template <int VAR>
+__global__ __launch_bounds__(GeoPP3::THREADS) void mfma_f16_pp3_kernel(const _Float16 *__restrict__ A,
+                                                                         const _Float16 *__restrict__ B,
+                                                                         _Float16 *__restrict__ C, unsigned N, unsigned K,
+                                                                         unsigned M, unsigned tiles_n, unsigned tiles_m,
+                                                                         unsigned kBand) {
+  using G = GeoPP3;
+  constexpr int RB = G::RB, NB = G::NB;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const unsigned lane = threadIdx.x & 63u;
+  const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const unsigned group = wave >> 2, wm = wave & 3u, wn = group;   // waves w and w + 4 share a SIMD
+  const unsigned l15 = lane & 15u, g = lane >> 4;
+
+  const unsigned lin = xcd_remap(blockIdx.x, tiles_n * tiles_m);
+  const unsigned band = lin / (kBand * tiles_m), within = lin % (kBand * tiles_m);
+  const unsigned rows_in_band = min(kBand, tiles_n - band * kBand);
+  const unsigned row0 = (band * kBand + within % rows_in_band) * G::BM, col0 = (within / rows_in_band) * G::BN;
+
+  // DMA: A stage = 24 pieces of 16 rows x 64 B (3 per wavefront), B stage = 16 pieces of 2 k-rows x 512 B (2 per wavefront)
+  unsigned voff_a[3], voff_b[2];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const unsigned row = (wave + 8 * i) * 16 + lane / 4, pc = lane % 4;
+    voff_a[i] = (min(row0 + row, N - 1) - row0) * K * 2 + (pc ^ ((0u - (row >> 2)) & 3u)) * 16;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const unsigned kr = (wave + 8 * i) * 2 + lane / 32, pb = lane % 32;
+    const unsigned lc = pb ^ ((kr & 3u) << 2) ^ (((kr >> 3) & 1u) << 1);
+    voff_b[i] = kr * M * 2 + (min(col0 + lc * 8, M - 8) - col0) * 2;
+  }
+  const char *a_base = (const char *)A + (size_t)row0 * K * 2;
+  const char *b_base = (const char *)B + (size_t)col0 * 2;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
+  const unsigned U = K / G::BK;
+  auto issue = [&](unsigned slab, unsigned buf) {
+    const unsigned sl = min(slab, U - 1);               // past the end: harmless re-fetch into a dead buffer
+    const char *ap = a_base + (size_t)sl * (G::BK * 2);
+    const char *bp = b_base + (size_t)sl * G::BK * M * 2;
+    const unsigned la0 = lds0 + buf * G::STAGE_BYTES + wave * 1024, la1 = la0 + 8 * 1024, la2 = la0 + 16 * 1024;
+    const unsigned lb0 = la0 + G::A_BYTES, lb1 = lb0 + 8 * 1024;
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\t" MM_DMA_PIECE("%1", "%6", "%8") MM_DMA_PIECE("%2", "%6", "%9") MM_DMA_PIECE("%3", "%6", "%10")
+                     MM_DMA_PIECE("%4", "%7", "%11") MM_DMA_PIECE("%5", "%7", "%12") "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff_a[0]), "v"(voff_a[1]), "v"(voff_a[2]), "v"(voff_b[0]), "v"(voff_b[1]), "s"(ap), "s"(bp), "s"(la0),
+                   "s"(la1), "s"(la2), "s"(lb0), "s"(lb1)
+                 : "memory");
+  };
+
+  // A: row = wm*96 + rb*16 + l15, chunk g, physical = g ^ (-(row>>2))&3 = g ^ (-(l15>>2))&3
+  const unsigned a_off = (wm * 96 + l15) * 64 + (g ^ ((0u - (l15 >> 2)) & 3u)) * 16;
+  // B: k = 8*g + 4*h2 + r (r = l15>>2), piece = l15&3; logical chunk = wn*16 + nb*2 + (piece>>1); physical = logical ^ X,
+  // X = (r<<2) ^ ((g&1)<<1) touches chunk bits 1..3, which is where nb sits: the address of block nb is
+  // base + (((2*nb) ^ X) << 4), one v_xad_u32 per block instead of eight address registers
+  const unsigned r = l15 >> 2, piece = l15 & 3u;
+  const unsigned b_x = ((r << 2) ^ ((g & 1u) << 1)) << 4;
+  const unsigned b_lane = G::A_BYTES + (8 * g + r) * G::BROW + (wn * 16 + (piece >> 1)) * 16 + (piece & 1u) * 8;
+
+  using f32x4 = __attribute__((ext_vector_type(4))) float;
+  f32x4 acc[RB][NB];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) acc[rb][nb] = (f32x4)0.0f;
+
+  auto sync = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // One slab: load segment (all 6 A operands, the first 4 of the 8 B operands, the DMA of slab u + 2) | barrier |
+  // compute segment (48 MFMAs; B operands 4..7 are read into the registers of 0..3 as those retire: 192 accumulator
+  // + 24 + 16 operand registers fit the 256 of a wavefront, 24 + 32 do not) | barrier.  Because the partner group
+  // still reads slab u - 1 from LDS during ITS compute segment, a refill may only target the buffer of slab u - 2:
+  // two slabs in flight instead of three (in cycles the same lead as the 256 x 256 kernel: 2 x 1536 vs 3 x 1024).
+  // LDS addresses are formed per phase from (lane part) + (stage offset held opaque in an SGPR): as loop invariants
+  // hipcc would keep one address register per (buffer, operand) alive across the loop and spill accumulators for them.
+  typedef s4 __attribute__((address_space(3))) * lds_s4_t;
+  typedef const h8 __attribute__((address_space(3))) * lds_h8_t;
+  auto read_b = [&](unsigned tb, int nb) {
+    const unsigned p = tb + (b_x ^ (unsigned)(nb * 32));
+    const s4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_t)(size_t)p);
+    const s4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_t)(size_t)(p + 4 * G::BROW));
+    return join(v0, v1);
+  };
+  const bool shifted = !(VAR & 2) && group == 1;
+  const bool early = !shifted;   // (lock-step ablation: everybody follows the early group's rules)
+  auto phase = [&](auto bufc, unsigned u) {
+    constexpr int BUF = decltype(bufc)::value;
+    unsigned so = lds0 + BUF * G::STAGE_BYTES;
+    asm volatile("" : "+s"(so));
+    const unsigned tb = b_lane + so, ta = a_off + so;
+    h8 af[RB], bf[4];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) bf[nb] = read_b(tb, nb);
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) af[rb] = *(lds_h8_t)(size_t)(ta + rb * 16 * 64);
+    // Refill protocol, asymmetric between the two groups (see the buffer-lifetime note above): the EARLY group (0) may
+    // only target the buffer of slab u - 2 (its partner still reads u - 1), issues slab u + 2 and retires its share of
+    // slab u + 1 at the END of its compute segment; the LATE group (1), one interval behind, finds the buffer of slab
+    // u - 1 free, issues slab u + 3 and retires its share of slab u + 1 at the end of its load segment -- the same barrier
+    // instance.  Every piece so has 3 (early) or 4 (late) barrier intervals to land before the first read of its slab.
+    if (early) {
+      issue(u + 2, (BUF + 2) & 3);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    } else {
+      issue(u + 3, (BUF + 3) & 3);
+      asm volatile("s_waitcnt vmcnt(10)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    sync();
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb)
+        acc[rb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[rb], bf[nb], acc[rb][nb], 0, 0, 0);
+      bf[nb] = read_b(tb, nb + 4);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb)
+        acc[rb][nb + 4] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[rb], bf[nb], acc[rb][nb + 4], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    if (early) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    sync();
+  };
+
+  issue(0, 0);
+  issue(1, 1);
+  if (!early) issue(2, 2);
+  if (early) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+  sync();
+  if (shifted) sync();
+  for (unsigned u = 0; u < U; u += 4) {
+    phase(std::integral_constant<int, 0>{}, u);
+    if (u + 1 < U) phase(std::integral_constant<int, 1>{}, u + 1);
+    if (u + 2 < U) phase(std::integral_constant<int, 2>{}, u + 2);
+    if (u + 3 < U) phase(std::integral_constant<int, 3>{}, u + 3);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (!shifted && !(VAR & 2)) sync();
+  sync();
+
+  // epilogue in two column halves of 64 (a wavefront's 96 x 128 part would need 24 KiB of staging, 8 x 24 > 160 KiB)
+  {
+    char *slice = smem + wave * (96 * 128);
+    using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+#pragma unroll
+    for (int hcol = 0; hcol < 2; ++hcol) {
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            *(_Float16 *)(slice + (rb * 16 + 4 * g + i) * 128 + (nb * 16 + l15) * 2) = (_Float16)acc[rb][hcol * 4 + nb][i];
+#pragma unroll
+      for (int it = 0; it < 96 * 8 / 64; ++it) {
+        const unsigned c = it * 64 + lane, row = c / 8, ch = c % 8;
+        const u32x4 v = *(const u32x4 *)(slice + row * 128 + ch * 16);
+        const unsigned grow = row0 + wm * 96 + row, gcol = col0 + wn * 128 + hcol * 64 + ch * 8;
+        if (grow < N && gcol < M) *(u32x4 *)(C + (size_t)grow * M + gcol) = v;
+      }
+    }
+  }
+}
 #undef MM_DMA_PIECE
 
 }  // namespace
@@ -954,6 +1147,17 @@ static int launch_pp2s(hipStream_t s, const Problem &p) {
   return (int)hipGetLastError();
 }
 
+template <int VAR>
+static int launch_pp3(hipStream_t s, const Problem &p) {
+  using G = GeoPP3;
+  const unsigned tiles_n = (p.n + G::BM - 1) / G::BM, tiles_m = (p.m + G::BN - 1) / G::BN;
+  static unsigned long long configured = 0;
+  if (int e = ensure_dynamic_lds((const void *)mfma_f16_pp3_kernel<VAR>, G::LDS_BYTES, configured)) return e;
+  hipLaunchKernelGGL((mfma_f16_pp3_kernel<VAR>), dim3(tiles_n * tiles_m), dim3(G::THREADS), G::LDS_BYTES, s,
+                     (const _Float16 *)p.a, (const _Float16 *)p.b, (_Float16 *)p.c, p.n, p.k, p.m, tiles_n, tiles_m, band_rows());
+  return (int)hipGetLastError();
+}
+
 int mfma_f16_tile(const Problem &p) {  // 0: 256x256, 4: 128x256
   static const TileCandidate cands[] = {{0, 256, 256, 1, 1.00}, {4, 128, 256, 1, 0.80}};
   return p.a_transposed ? 0 : pick_tile(cands, 2, p.n, p.m);
@@ -966,6 +1170,8 @@ int launch_mfma_f16(hipStream_t s, const Problem &p) {
     if (v != 0 && mfma_f16_pp_at_serves(p)) return launch_pp<1, true>(s, p);
     return launch_h<GeoH, true>(s, p);
   }
+  if (v == 300 && mfma_f16_pp_serves(p)) return launch_pp3<0>(s, p);    // 384 x 256 tile, 16x16x32
+  if (v == 302 && mfma_f16_pp_serves(p)) return launch_pp3<2>(s, p);
   if (v == 200 && mfma_f16_pp2_serves(p)) return launch_pp2s<0>(s, p);   // 16x16x32 matrix instruction
   if (v == 202 && mfma_f16_pp2_serves(p)) return launch_pp2s<2>(s, p);   // its lock-step ablation
   if (v >= 100 && v < 200 && mfma_f16_pp2_serves(p)) {  // 100 + VAR of the full-line-A ping-pong kernel
@@ -1009,7 +1215,7 @@ int launch_mfma_f16(hipStream_t s, const Problem &p) {
   // default: the shape-adaptive tile pick; where that is the 256 x 256 tile and the shape allows it,
   // the ping-pong schedule (84-89 % MFMA utilisation vs 67 %, profiles/r02d_pmc_f16_32768_v*.json)
   if (mfma_f16_tile(p) == 4) return launch_h<GeoHS>(s, p);
-  if (mfma_f16_pp2_serves(p)) return launch_pp2<0>(s, p);  // +2-4 % over pp: one L2 request per A line (profiles/r02h_*)
+  if (mfma_f16_pp2_serves(p)) return launch_pp2s<0>(s, p);  // 16x16x32 instruction: +7 % over pp2 (profiles/r03c_*); pp2: +2-4 % over pp (r02h_*)
   if (mfma_f16_pp_serves(p)) return launch_pp<1>(s, p);
   return launch_h<GeoH>(s, p);
 }

@@ -587,6 +587,166 @@ __global__ __launch_bounds__(GeoI8PP2::THREADS) void mfma_i8_pp2_kernel(const si
     }
   }
 }
+
+// Ping-pong kernel on v_mfma_i32_16x16x64_i8 ("pp2s", round 3): same tile, rings, DMA and segment protocol as
+// pp2, the matrix instruction in its 16 x 16 x 64 form (4 accumulator registers, 16 cycles) -- on full-range random
+// bytes the register-only loop of this form holds 1.97 GHz = 4.09 POp/s where the 32x32x32 form holds 1.67 GHz =
+// 3.50 POp/s (profiles/r03b_probe_mfma_power_by_shape_and_operand_order.txt), and the kernel is power-limited.
+// A wavefront's 128 x 64 block is 8 x 4 accumulators; a 64-deep slab is ONE MFMA k: 8 A operands (ds_read_b128:
+// row l&15, k = 16*(l>>4)..+15) and 4 B operands (two ds_read_b64_tr_b8 each: lane group l>>4 gathers
+// k = 16*(l>>4)..+15 of 16 columns).  B image [64 k][256 cols]: a half-wave's two lane groups differ in k by 16
+// instead of in column by 16, so the chunk index is XORed with ((k&7)<<1) | ((k>>4)&1): the 16 k-rows a half-wave
+// touches fall into the 16 different chunks of the 256-byte bank row.  Integer sums: bit-identical to every
+// other schedule and to Naive.
+template <int VAR>
+__global__ __launch_bounds__(GeoI8PP2::THREADS) void mfma_i8_pp2s_kernel(const signed char *__restrict__ A,
+                                                                          const signed char *__restrict__ B,
+                                                                          signed char *__restrict__ C, unsigned N, unsigned K,
+                                                                          unsigned M, unsigned tiles_n, unsigned tiles_m,
+                                                                          unsigned kBand) {
+  using G = GeoI8PP2;
+  constexpr int RB = 8, NB = 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const unsigned lane = threadIdx.x & 63u;
+  const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const unsigned group = wave >> 2, wq = wave & 3u;
+  const unsigned wm = wq >> 1, wn = (wq & 1u) * 2 + group;
+  const unsigned l15 = lane & 15u, g = lane >> 4;
+
+  const unsigned lin = xcd_remap(blockIdx.x, tiles_n * tiles_m);
+  const unsigned band = lin / (kBand * tiles_m), within = lin % (kBand * tiles_m);
+  const unsigned rows_in_band = min(kBand, tiles_n - band * kBand);
+  const unsigned row0 = (band * kBand + within % rows_in_band) * G::BM, col0 = (within / rows_in_band) * G::BN;
+
+  unsigned voff_a[4], voff_b[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const unsigned row = (wave + 8 * i) * 8 + lane / 8, pc = lane % 8;
+    voff_a[i] = (min(row0 + row, N - 1) - row0) * K + (pc ^ ((row >> 1) & 7u)) * 16;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const unsigned kr = (wave + 8 * i) * 4 + lane / 16, pb = lane % 16;
+    const unsigned lc = pb ^ (((kr & 7u) << 1) | ((kr >> 4) & 1u));
+    voff_b[i] = kr * M + (min(col0 + lc * 16, M - 16) - col0);
+  }
+  const char *a_base = (const char *)A + (size_t)row0 * K;
+  const char *b_base = (const char *)B + col0;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
+  const unsigned U = K / G::BK, UD = U / 2;
+  auto issue_a = [&](unsigned ds, unsigned abuf, int h) {
+    const char *ap = a_base + (size_t)min(ds, UD - 1) * 128;
+    const unsigned la0 = lds0 + abuf * G::A2_BYTES + (wave + 16 * h) * 1024, la1 = la0 + 8 * 1024;
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\t" MM_DMA_PIECE("%1", "%3", "%4") MM_DMA_PIECE("%2", "%3", "%5") "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(h ? voff_a[2] : voff_a[0]), "v"(h ? voff_a[3] : voff_a[1]), "s"(ap), "s"(la0), "s"(la1)
+                 : "memory");
+  };
+  auto issue_b = [&](unsigned slab, unsigned bbuf) {
+    const char *bp = b_base + (size_t)min(slab, U - 1) * G::BK * M;
+    const unsigned lb0 = lds0 + G::B_REGION + bbuf * G::B_BYTES + wave * 1024, lb1 = lb0 + 8 * 1024;
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\t" MM_DMA_PIECE("%1", "%3", "%4") MM_DMA_PIECE("%2", "%3", "%5") "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff_b[0]), "v"(voff_b[1]), "s"(bp), "s"(lb0), "s"(lb1)
+                 : "memory");
+  };
+
+  // A: row = wm*128 + rb*16 + l15, logical chunk 4*H + g, physical = logical ^ (row>>1)&7
+  const unsigned a_row_byte = (wm * 128 + l15) * 128;
+  const unsigned a_off[2] = {a_row_byte + (g ^ (l15 >> 1)) * 16, a_row_byte + ((4u + g) ^ (l15 >> 1)) * 16};
+  // B (8-bit transpose read): block row r = l15>>1 (k = 16*g + 8*h2 + r), 8-byte half q = l15&1 of the 16 columns
+  const unsigned r = l15 >> 1, q = l15 & 1u;
+  unsigned b_off[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+    b_off[nb] = G::B_REGION + (16 * g + r) * G::BROW + 8 * q + ((wn * 4 + nb) ^ ((r << 1) | (g & 1u))) * 16;
+
+  i32x4 acc[RB][NB];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) acc[rb][nb] = (i32x4)0;
+
+  auto sync = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto phase = [&](auto bufc, unsigned u, unsigned abuf) {
+    constexpr int BUF = decltype(bufc)::value;
+    constexpr int H = BUF & 1;
+    const char *abase = smem + abuf * G::A2_BYTES;
+    const char *bbase = smem + BUF * G::B_BYTES;
+    i32x4 af[RB], bf[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      const char *p = bbase + b_off[nb];
+      const v2i v0 = __builtin_amdgcn_ds_read_tr8_b64_v2i32((v2i __attribute__((address_space(3))) *)(lptr_t)p);
+      const v2i v1 = __builtin_amdgcn_ds_read_tr8_b64_v2i32((v2i __attribute__((address_space(3))) *)(lptr_t)(p + 8 * G::BROW));
+      bf[nb] = join(v0, v1);
+    }
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) af[rb] = *(const i32x4 *)(abase + a_off[H] + rb * 16 * 128);
+    issue_a(u / 2 + 2, abuf >= 1 ? abuf - 1 : 2, H);
+    issue_b(u + 3, (BUF + 3) & 3);
+    asm volatile("s_waitcnt vmcnt(8)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+    sync();
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+        acc[rb][nb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[rb], bf[nb], acc[rb][nb], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    sync();
+  };
+
+  issue_a(0, 0, 0);
+  issue_a(0, 0, 1);
+  issue_b(0, 0);
+  issue_a(1, 1, 0);
+  issue_b(1, 1);
+  issue_a(1, 1, 1);
+  issue_b(2, 2);
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  sync();
+  const bool shifted = !(VAR & 2) && group == 1;
+  if (shifted) sync();
+  unsigned ab = 0;
+  for (unsigned u = 0; u < U; u += 4) {
+    const unsigned ab1 = ab == 2 ? 0 : ab + 1;
+    phase(std::integral_constant<int, 0>{}, u, ab);
+    phase(std::integral_constant<int, 1>{}, u + 1, ab);
+    if (u + 2 < U) {
+      phase(std::integral_constant<int, 2>{}, u + 2, ab1);
+      phase(std::integral_constant<int, 3>{}, u + 3, ab1);
+    }
+    ab = ab1 == 2 ? 0 : ab1 + 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (!shifted && !(VAR & 2)) sync();
+  sync();
+
+  {  // C/D of the 16x16 form: column l15, rows 4*g + i
+    char *slice = smem + wave * (128 * 64);
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) slice[(rb * 16 + 4 * g + i) * 64 + nb * 16 + l15] = (char)acc[rb][nb][i];
+    using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+#pragma unroll
+    for (int it = 0; it < 128 * 4 / 64; ++it) {
+      const unsigned c = it * 64 + lane, row = c / 4, ch = c % 4;
+      const u32x4 v = *(const u32x4 *)(slice + row * 64 + ch * 16);
+      const unsigned grow = row0 + wm * 128 + row, gcol = col0 + wn * 64 + ch * 16;
+      if (grow < N && gcol < M) *(u32x4 *)(C + (size_t)grow * M + gcol) = v;
+    }
+  }
+}
 #undef MM_DMA_PIECE
 
 }  // namespace
@@ -633,13 +793,25 @@ static int launch_i8_pp2(hipStream_t s, const Problem &p) {
   return (int)hipGetLastError();
 }
 
+static int launch_i8_pp2s(hipStream_t s, const Problem &p) {
+  using G = GeoI8PP2;
+  const unsigned tiles_n = (p.n + G::BM - 1) / G::BM, tiles_m = (p.m + G::BN - 1) / G::BN;
+  static unsigned long long configured = 0;
+  if (int e = ensure_dynamic_lds((const void *)mfma_i8_pp2s_kernel<0>, G::LDS_BYTES, configured)) return e;
+  hipLaunchKernelGGL((mfma_i8_pp2s_kernel<0>), dim3(tiles_n * tiles_m), dim3(G::THREADS), G::LDS_BYTES, s,
+                     (const signed char *)p.a, (const signed char *)p.b, (signed char *)p.c, p.n, p.k, p.m, tiles_n, tiles_m,
+                     band_rows());
+  return (int)hipGetLastError();
+}
+
 int launch_mfma_i8(hipStream_t s, const Problem &p) {
   if (!mfma_i8_serves(p)) return kErrNotSupported;
   // i8_variant knob: 0 = one-slab-per-barrier kernel, 10 = ping-pong, 12 = ping-pong in lock step
   // (ablation), 100 = ping-pong with full-line A requests; default: the best the shape allows
   const int v = tuning(TUNE_I8_VARIANT);
   if (mfma_i8_pp_at_serves(p) && v != 0) return launch_i8_pp<0, true>(s, p);  // K x N A on the ping-pong schedule
-  if (mfma_i8_pp2_serves(p) && (v < 0 || v == 100)) return launch_i8_pp2(s, p);
+  if (mfma_i8_pp2_serves(p) && (v < 0 || v == 200)) return launch_i8_pp2s(s, p);   // 16x16x64 matrix instruction: +7.6 % (profiles/r03e_*)
+  if (mfma_i8_pp2_serves(p) && v == 100) return launch_i8_pp2(s, p);
   if (mfma_i8_pp_serves(p) && v != 0) return v == 12 ? launch_i8_pp<2>(s, p) : launch_i8_pp<0>(s, p);
   using G = GeoI8;
   const unsigned tiles_n = (p.n + G::BM - 1) / G::BM, tiles_m = (p.m + G::BN - 1) / G::BN;

@@ -160,7 +160,7 @@ def test_f16_mfma_wide_accumulate_contract(shape):
     assert rel.max() <= 2.0 ** -11 * 1.01      # half an ulp of binary16 relative to the exact value (+f32 noise)
 
 
-@pytest.mark.parametrize("variant", [10, 11, 12, 13, 14, 15, 19, 23, 100, 102, 200, 202, 0, 1, 4])
+@pytest.mark.parametrize("variant", [10, 11, 12, 13, 14, 15, 19, 23, 100, 102, 200, 202, 300, 302, 0, 1, 4])
 @pytest.mark.parametrize("shape", [(513, 544, 528), (300, 128, 272), (257, 1056, 520), (1024, 4096, 1024), (129, 160, 264),
                                    (770, 2048, 1288), (300, 256, 272), (513, 576, 528), (260, 320, 264)],
                          ids=lambda s: "x".join(map(str, s)))
@@ -222,7 +222,7 @@ def test_i8_mfma_is_bit_exact_mod_256(dtype, shape):
 
 
 @pytest.mark.parametrize("dtype", ["int8_t", "uint8_t"])
-@pytest.mark.parametrize("variant", [-1, 0, 10, 12, 100])
+@pytest.mark.parametrize("variant", [-1, 0, 10, 12, 100, 200])
 @pytest.mark.parametrize("shape", [(513, 576, 528), (300, 4160, 272), (257, 256, 1040), (1024, 1024, 1024), (1, 320, 16),
                                    (513, 640, 528), (300, 4224, 272), (260, 512, 1040)],
                          ids=lambda s: "x".join(map(str, s)))
@@ -257,7 +257,11 @@ def test_f16_i8_transposed_a_on_the_pingpong_schedule(dtype, shape):
         b = rng.integers(0, 256, size=(k, m), dtype=np.uint8).view(_oracle.NP_DTYPES[dtype])
     at = np.ascontiguousarray(a.T)
     knob = "f16_variant" if dtype == "half" else "i8_variant"
+    # the row-major default now runs the 16x16x32 matrix instruction (a different fp32 summation order inside an MFMA);
+    # the K x N kernels are on the 32x32x16 form, so for half the bitwise layout check pins the row-major side to it too
+    g.set_tuning(knob, 11 if dtype == "half" else -1)
     c_rm, _ = g.matmul_capi(a, b, dtype)
+    g.set_tuning(knob, -1)
     c_at, _ = g.matmul_capi(at, b, dtype, transposed_a=True)
     g.set_tuning(knob, 0)
     c_old, _ = g.matmul_capi(at, b, dtype, transposed_a=True)
