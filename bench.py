@@ -116,21 +116,54 @@ def cpu_baseline(sample_n=1024):
     return info
 
 
-def hbm_traffic_per_launch():
-    """HBM-side bytes per launch of the headline kernel.  NOT measured in this run: rocprofv3's PMC
-    passes serialise and slow the kernel, so they are collected separately by tools/pmc_traffic.py
-    (separate --pmc FETCH_SIZE / WRITE_SIZE passes, the guide's gfx950 correction) and committed
-    under profiles/; this returns (bytes, source file) of the latest round's file, or (None, None)."""
+def replayed_counters(kernel_name, shape):
+    """Counters of the kernel this run dispatched, REPLAYED from committed rocprofv3 PMC files (the counter passes
+    serialise and slow the kernel, so they are collected separately: tools/pmc_traffic.py = FETCH_SIZE / WRITE_SIZE in
+    separate --pmc passes with the guide's gfx950 correction, tools/pmc_mfma.py = SQ / GRBM / TCC passes).  A file is
+    used only if it says it profiled THIS kernel (`kernel_name` == mm_kernel_name of the run) on THIS shape; the
+    newest matching file of each kind wins.  Returns {} when nothing matches -- never another kernel's numbers."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))  # rNN[x]_ prefixes sort by round
+    out = {}
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*.json")))  # rNN[x]_ prefixes sort by round
     for path in reversed(files):
         try:
             d = json.load(open(path))
         except Exception:
             continue
-        if d.get("hbm_bytes_per_launch") and d.get("workload", "float") == "float":
-            return d["hbm_bytes_per_launch"], os.path.relpath(path, ROOT)
-    return None, None
+        if not isinstance(d, dict) or d.get("kernel_name") != kernel_name:
+            continue
+        dshape = list(d["shape"]) if "shape" in d else [d.get("size")] * 3
+        if dshape != list(shape):
+            continue
+        rel = os.path.relpath(path, ROOT)
+        if "hbm_bytes_per_launch" in d and "traffic" not in out:
+            out["traffic"] = d["hbm_bytes_per_launch"]
+            out["traffic_source"] = rel
+        if "MfmaUtil_pct" in d and "mfma_util_pct" not in out:
+            out["mfma_util_pct"] = round(d["MfmaUtil_pct"], 2)
+            out["profiled_clock_GHz"] = round(d.get("effective_clock_GHz_profiled", 0.0), 3)
+            if "L2_hit_rate" in d:
+                out["l2_hit_rate"] = round(d["L2_hit_rate"], 4)
+            out["mfma_util_source"] = rel
+    return out
+
+
+def attach_replayed(roofline, kernel_name, shape):
+    """Adds the replayed counters to a roofline object; `achieved_fabric_GBps` = replayed bytes per launch over the
+    launch time measured live in this run."""
+    rc = replayed_counters(kernel_name, shape)
+    if not rc:
+        roofline["traffic_note"] = (f"no committed PMC file names kernel {kernel_name!r} at {list(shape)}: traffic and MFMA "
+                                    "utilisation not reported rather than replayed from another kernel")
+        return roofline
+    roofline.update(rc)
+    if "traffic" in rc:
+        roofline["achieved_fabric_GBps"] = round(rc["traffic"] / (1e-3 * roofline["avg_launch_ms"]) / 1e9, 1)
+    roofline["traffic_note"] = ("traffic (L2 <-> fabric bytes per launch, Infinity-Cache hits included), mfma_util_pct, "
+                                "profiled_clock_GHz and l2_hit_rate are REPLAYED from the committed rocprofv3 PMC files "
+                                "named in *_source, which profiled this same kernel on this shape; they are not measured "
+                                "in this run")
+    return roofline
 
 
 def timed_steps(g, torch, a, b, c, dtype, map_op, reduce_op, steps, warmup, barrier, path=0):
@@ -200,6 +233,7 @@ def extra_workloads(g, torch, dev, local_rank, steps=5):
                      "dtype": DTYPE_TAG[dtype], "value": round(value, 1), "unit": "GOp/s", "steps": steps, "warmup": 2,
                      "ms_per_step": round(1e3 * elapsed / steps, 4),
                      "roofline": roofline_obj(dtype, roof, peak, rows, k, m, launch_ms)}
+            attach_replayed(entry["roofline"], entry["kernel"], (rows, k, m))
             if key == "float_split":
                 entry["workload"] += "; MM_PATH_SPLIT (opt-in), split + re-tile pre-pass inside the timed step"
                 entry["dtype"] = "f32 in/out; operands as 3 bf16 planes, 6 bf16 MFMA products per pair, f32 accumulate"
@@ -352,11 +386,9 @@ def main():
         flops_job = 2.0 * n_total * k * m
         value = 1e-9 * flops_job * args.steps / elapsed
         rl = roofline_obj(dtype, roof, peak, rows, k, m, launch_ms)
-        if headline and world == 1 and n_total == SIZE:
-            rl["traffic"], rl["traffic_source"] = hbm_traffic_per_launch()
-            if rl["traffic"] is not None:
-                rl["traffic_note"] = ("HBM-side bytes per launch replayed from the committed rocprofv3 PMC passes named in "
-                                      "traffic_source (collected by tools/pmc_traffic.py), not measured in this run")
+        if world == 1:
+            attach_replayed(rl, g.kernel_name(g.make_config(dtype, map_op, reduce_op, PATHS.get(args.workload, 0)), rows, k, m),
+                            (rows, k, m))
         if world == 1:
             what = f"{dtype} {n_total}x{k}x{m} ({map_op},{reduce_op}) on 1 MI355X" + ("; BASELINE configs[1]" if headline else "")
         elif scaling == "strong":

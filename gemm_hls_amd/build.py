@@ -24,7 +24,9 @@ BIN = os.path.join(ROOT, "bin")
 LIB = os.path.join(HERE, "libmm_gemm_amd.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
-COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+# --offload-compress: the device code objects are stored zstd-compressed (the generic-semiring families are 11 types x
+# 25 operator pairs of kernels; 7.3 MB -> ~2 MB), the runtime inflates them when the library is loaded
+COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "--offload-compress"]
 # per-file extra flags
 EXTRA = {
     # the parity anchor must not contract a*b+c into an fma (reference Naive is unfused)
@@ -57,6 +59,34 @@ def run(cmd):
         sys.stderr.write(r.stderr)
 
 
+LAB_DIR = os.path.join(ROOT, "tools", "lab")
+LAB_LIB = os.path.join(LAB_DIR, "libmm_gemm_amd_lab.so")
+LAB_REPLACES = {"lab_mfma_f32.hip": "mm_mfma_f32.o", "lab_mfma_f16.hip": "mm_mfma_f16.o", "lab_mfma_i8.hip": "mm_mfma_i8.o",
+                "lab_mfma_f32_split.hip": "mm_mfma_f32_split.o"}
+
+
+def build_lab(product_objs, headers, verbose=True):
+    """tools/lab/libmm_gemm_amd_lab.so: the SAME C ABI with the four matrix-core translation units swapped for their
+    lab editions (every schedule / ring depth / ablation the kernels went through, incl. the ones that skip work on
+    purpose).  Measurement tooling only (MM_LIB=lab for tools/sweep.py and friends); nothing in the product links it."""
+    if not os.path.isdir(LAB_DIR):
+        return
+    os.makedirs(os.path.join(LAB_DIR, "_obj"), exist_ok=True)
+    jobs, lab_objs = [], []
+    for src, replaced in LAB_REPLACES.items():
+        obj = os.path.join(LAB_DIR, "_obj", src[:-4] + ".o")
+        lab_objs.append(obj)
+        if newer(obj, [os.path.join(LAB_DIR, src)] + headers + [__file__]):
+            jobs.append([HIPCC] + COMMON + ["-DMM_LAB_BUILD", "-c", os.path.join(LAB_DIR, src), "-o", obj])
+    with concurrent.futures.ThreadPoolExecutor(max_workers=os.cpu_count() or 4) as ex:
+        list(ex.map(run, jobs))
+    keep = [o for o in product_objs if os.path.basename(o) not in LAB_REPLACES.values()]
+    if jobs or newer(LAB_LIB, keep + lab_objs):
+        run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "--offload-compress", "-o", LAB_LIB] + keep + lab_objs)
+    if verbose:
+        print(f"built {LAB_LIB} ({len(jobs)} lab objects recompiled)")
+
+
 def build(verbose=True):
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(BIN, exist_ok=True)
@@ -73,9 +103,10 @@ def build(verbose=True):
     with concurrent.futures.ThreadPoolExecutor(max_workers=os.cpu_count() or 4) as ex:
         list(ex.map(run, jobs))
     if jobs or newer(LIB, objs):   # also after an object was rebuilt by hand
-        run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs)
+        run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "--offload-compress", "-o", LIB] + objs)
     if verbose:
         print(f"built {LIB} ({len(jobs)} objects recompiled)")
+    build_lab(objs, headers, verbose)
 
     host_dir = os.path.join(HERE, "host")
     host_jobs = []

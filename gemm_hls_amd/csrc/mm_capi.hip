@@ -117,10 +117,7 @@ bool valid_cfg(const mm_config_t *cfg) {
 // The f32_variant knob selects another one for sweeps (tools/sweep.py); -1 = shape-adaptive choice
 // among the flush-capable geometries (mm_mfma_f32.hip).
 int f32_variant() { return mm::tuning(mm::TUNE_F32_VARIANT); }
-int f32_variant_for(const mm::Problem &p) {
-  const int v = f32_variant();
-  return v >= 0 ? v : (p.a_transposed ? 8 : mm::mfma_f32_auto_variant(p));
-}
+int f32_variant_for(const mm::Problem &p) { return mm::mfma_f32_resolve(p, f32_variant()); }  // what the launcher runs; -1: none
 
 enum Family { FAM_ORDERED, FAM_VALU_TILE, FAM_MFMA_F32, FAM_MFMA_F64, FAM_MFMA_F16, FAM_MFMA_I8, FAM_HALF_WIDE,
               FAM_F32_SPLIT, FAM_NONE };
@@ -246,16 +243,9 @@ int mm_free(int device, void *device_ptr) {
 int mm_release_workspace(int device) {
   int rc = check_device(device);
   if (rc) return rc;
-  hipMemPool_t pool;
   MM_HIP(hipSetDevice(device));
-  MM_HIP(hipDeviceGetDefaultMemPool(&pool, device));
-  // the launch path raised the pool's release threshold so that freed workspace stays cached; drop it to 0 for
-  // the duration of a synchronisation (which is when the runtime releases), trim, and raise it again
-  unsigned long long none = 0, keep = ~0ull;
-  MM_HIP(hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &none));
-  MM_HIP(hipDeviceSynchronize());
-  MM_HIP(hipMemPoolTrimTo(pool, 0));
-  MM_HIP(hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep));
+  MM_HIP(hipDeviceSynchronize());   // stream-ordered frees are complete: everything the pool holds is reclaimable
+  MM_HIP((hipError_t)mm::mfma_f32_split_release(device));
   return MM_OK;
 }
 
@@ -530,10 +520,11 @@ const char *mm_kernel_name(const mm_config_t *cfg, unsigned n, unsigned k, unsig
   if (!valid_cfg(cfg)) return "invalid";
   mm::Problem p{nullptr, nullptr, nullptr, n, k, m, cfg->layout_a == MM_A_TRANSPOSED};
   switch (choose(*cfg, p)) {
-    case FAM_MFMA_F32: return mm::mfma_f32_name(f32_variant_for(p));
-    case FAM_MFMA_F64: return "mfma_f64";
-    case FAM_MFMA_F16: return "mfma_f16";
-    case FAM_MFMA_I8: return "mfma_i8";
+    // every family answers through the same resolver its launcher uses, so the name IS the kernel that runs
+    case FAM_MFMA_F32: return f32_variant_for(p) < 0 ? "unsupported" : mm::mfma_f32_name(f32_variant_for(p));
+    case FAM_MFMA_F64: return mm::mfma_f64_name(p);
+    case FAM_MFMA_F16: return mm::mfma_f16_name(p);
+    case FAM_MFMA_I8: return mm::mfma_i8_name(p);
     case FAM_HALF_WIDE: return "ordered_wide_f16";
     case FAM_F32_SPLIT: return "mfma_f32_split_bf16x3";
     case FAM_NONE: return "unsupported";
@@ -561,21 +552,26 @@ int mm_kernel_info(const mm_config_t *cfg, unsigned n, unsigned k, unsigned m, m
       r.inst_n = 16; r.inst_m = 16; r.inst_k = 4; r.ops_per_clk_per_cu = 128.0;
       r.measured_issue_efficiency = 0.97;  // pinned schedule + scalar-base DMA: 76.4 TF of 78.6 (profiles/r02z_f64_scalar_base_dma.log)
       break;
-    case FAM_MFMA_F16:
-      if (mm::mfma_f16_tile(p) == 4) { r.tile_n = 128; r.tile_m = 256; r.wavefronts = 4; }
-      else { r.tile_n = 256; r.tile_m = 256; r.wavefronts = 8; }
-      r.tile_k = (r.tile_n == 256 && k % 32 == 0 && k >= 128 && cfg->layout_a == MM_A_ROW_MAJOR) ? 32 : 64;
-      r.inst_n = 32; r.inst_m = 32; r.inst_k = 16; r.ops_per_clk_per_cu = 4096.0;
-      // ping-pong schedule: MfmaUtil 89.7 % at 32768^3 (profiles/r02i_pmc_f16_32768_v100.json); the chip is
-      // power-limited there and delivers ~1.45 GHz, so 0.90 x 2.4 GHz over-predicts wall throughput
-      r.measured_issue_efficiency = r.tile_k == 32 ? 0.90 : 0.67;
+    case FAM_MFMA_F16: {
+      const std::string name = mm::mfma_f16_name(p);   // geometry read off the resolved kernel's name
+      const bool s16 = name.find("16x16x32") != std::string::npos, pp = name.find("pingpong") != std::string::npos;
+      r.tile_n = name.find("128x256") != std::string::npos ? 128 : 256; r.tile_m = 256; r.wavefronts = r.tile_n == 256 ? 8 : 4;
+      r.tile_k = pp ? 32 : 64;
+      r.inst_n = r.inst_m = s16 ? 16 : 32; r.inst_k = s16 ? 32 : 16; r.ops_per_clk_per_cu = 4096.0;
+      // ping-pong schedule: MfmaUtil 91.4 % (16x16x32, profiles/r03g_pmc_f16_32768_16x16x32.json) / 89.7 % (32x32x16) at
+      // 32768^3; the chip is power-limited there and delivers ~1.5 GHz, so 0.91 x 2.4 GHz over-predicts wall throughput
+      r.measured_issue_efficiency = pp ? (s16 ? 0.91 : 0.90) : 0.67;
       break;
-    case FAM_MFMA_I8:
+    }
+    case FAM_MFMA_I8: {
+      const std::string name = mm::mfma_i8_name(p);
+      const bool s16 = name.find("16x16x64") != std::string::npos, pp = name.find("pingpong") != std::string::npos;
       r.tile_n = 256; r.tile_m = 256; r.wavefronts = 8;
-      r.tile_k = (k % 64 == 0 && k >= 256 && cfg->layout_a == MM_A_ROW_MAJOR) ? 64 : 128;
-      r.inst_n = 32; r.inst_m = 32; r.inst_k = 32; r.ops_per_clk_per_cu = 8192.0;
-      r.measured_issue_efficiency = r.tile_k == 64 ? 0.92 : 0.68;  // profiles/r02i_pmc_i8_32768.json / r01_pmc_i8.json
+      r.tile_k = pp ? 64 : 128;
+      r.inst_n = r.inst_m = s16 ? 16 : 32; r.inst_k = s16 ? 64 : 32; r.ops_per_clk_per_cu = 8192.0;
+      r.measured_issue_efficiency = pp ? 0.92 : 0.68;  // profiles/r02i_pmc_i8_32768.json / r01_pmc_i8.json
       break;
+    }
     case FAM_F32_SPLIT:
       r.tile_n = r.tile_m = (unsigned)mm::mfma_f32_split_tile(p, mm::tuning(mm::TUNE_SPLIT_VARIANT));
       r.tile_k = 16; r.wavefronts = r.tile_n == 256 ? 8 : 4;

@@ -89,6 +89,7 @@ int launch_mfma_f32_split(hipStream_t s, const Problem &p, int variant);  // MM_
 bool mfma_f32_split_serves(const Problem &p);
 size_t mfma_f32_split_workspace_bytes(const Problem &p);
 int mfma_f32_split_tile(const Problem &p, int variant);  // 256 or 128
+int mfma_f32_split_release(int device);                  // trims the library-owned workspace pool of `device`
 bool mfma_f32_serves(const Problem &p);
 bool mfma_f64_serves(const Problem &p);
 bool mfma_f16_serves(const Problem &p);
@@ -96,6 +97,11 @@ bool mfma_i8_serves(const Problem &p);
 const char *mfma_f32_name(int variant);
 void mfma_f32_geometry(int variant, unsigned *bm, unsigned *bn, unsigned *bk, unsigned *waves);
 int mfma_f32_num_variants();
+int mfma_f32_variant_id(int index);                      // the valid f32_variant values, 0 <= index < num_variants
+int mfma_f32_resolve(const Problem &p, int variant);     // variant id a (problem, knob) pair runs, -1 = unsupported
+const char *mfma_f16_name(const Problem &p);
+const char *mfma_f64_name(const Problem &p);
+const char *mfma_i8_name(const Problem &p);
 int mfma_f32_auto_variant(const Problem &p);
 int mfma_f64_tile(const Problem &p);  // 0: 256x128, 1: 128x128
 int mfma_f16_tile(const Problem &p);  // 0: 256x256, 4: 128x256  // shape-adaptive pick (variant < 0)
@@ -135,13 +141,22 @@ enum Tunable {
 int tuning(Tunable t);  // mm_capi.hip
 
 // Tile rasterisation: after the XCD remap, workgroups are ordered in bands of `band_rows` tile-rows
-// (column-major inside a band), so the 32 workgroups an XCD runs at once cover
-// band_rows x (32/band_rows) tiles and share A row-panels / B column-panels in that XCD's L2.
-// 4 measured best on the fp32 kernel (fabric fetch 30 GB per 16384^3 launch vs 51 GB at 8 and
-// 100 GB at 16; profiles/r01_band_rows_sweep.txt).
-inline unsigned band_rows() {
+// (column-major inside a band), so the T = 32 x per_cu workgroups an XCD runs at once cover
+// band_rows x (T / band_rows) tiles and share A row-panels / B column-panels in that XCD's L2.  What the XCD then
+// pulls through the fabric per round is band_rows x BM rows of A plus (T / band_rows) x BN columns of B: the default is
+// the power of two that minimises that sum (ties: the smaller band).  256 x 256 tiles, one per CU: 4 (measured on the
+// fp32 kernel: fabric fetch 30 GB per 16384^3 launch vs 51 GB at 8 and 100 GB at 16, profiles/r01_band_rows_sweep.txt);
+// 128-row tiles running two workgroups per CU: 8 (round 3: the 128 x 256 fp32 default fetched 50 GB with bands of 4).
+inline unsigned band_rows(unsigned bm = 256, unsigned bn = 256, unsigned per_cu = 1) {
   const int v = tuning(TUNE_BAND_ROWS);
-  return v > 0 ? (unsigned)v : 4u;
+  if (v > 0) return (unsigned)v;
+  const unsigned t = 32u * per_cu;
+  unsigned best = 4, cost = ~0u;
+  for (unsigned r = 1; r <= t; r *= 2) {
+    const unsigned c = r * bm + (t / r) * bn;
+    if (c < cost) { cost = c; best = r; }
+  }
+  return best;
 }
 
 // Shape-adaptive tile choice shared by the MFMA families.  A launch runs in rounds of resident

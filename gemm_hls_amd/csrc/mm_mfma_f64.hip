@@ -340,12 +340,14 @@ static int launch_d(hipStream_t s, const Problem &p) {
   if (p.a_transposed) {
     if (int e = ensure_dynamic_lds((const void *)mfma_f64_kernel<G, true>, G::LDS_BYTES, configured_at)) return e;
     hipLaunchKernelGGL((mfma_f64_kernel<G, true>), dim3(tiles_n * tiles_m), dim3(G::THREADS), G::LDS_BYTES, s,
-                       (const double *)p.a, (const double *)p.b, (double *)p.c, p.n, p.k, p.m, tiles_n, tiles_m, band_rows());
+                       (const double *)p.a, (const double *)p.b, (double *)p.c, p.n, p.k, p.m, tiles_n, tiles_m,
+                       band_rows(G::BM, G::BN, G::BM * G::BN <= 128 * 128 ? 2 : 1));
     return (int)hipGetLastError();
   }
   if (int e = ensure_dynamic_lds((const void *)mfma_f64_kernel<G, false>, G::LDS_BYTES, configured)) return e;
   hipLaunchKernelGGL((mfma_f64_kernel<G, false>), dim3(tiles_n * tiles_m), dim3(G::THREADS), G::LDS_BYTES, s,
-                     (const double *)p.a, (const double *)p.b, (double *)p.c, p.n, p.k, p.m, tiles_n, tiles_m, band_rows());
+                     (const double *)p.a, (const double *)p.b, (double *)p.c, p.n, p.k, p.m, tiles_n, tiles_m,
+                       band_rows(G::BM, G::BN, G::BM * G::BN <= 128 * 128 ? 2 : 1));
   return (int)hipGetLastError();
 }
 
@@ -358,13 +360,31 @@ int mfma_f64_tile(const Problem &p) {  // 0: 256x128, 1: 128x128
   return pick_tile(cands, 2, p.n, p.m);
 }
 
-int launch_mfma_f64(hipStream_t s, const Problem &p) {
-  if (!mfma_f64_serves(p)) return kErrNotSupported;
+// One resolver for mm_kernel_name and the launcher: bit 0 = the 128 x 128 tile, bit 1 = the compiler-placed schedule
+// with per-lane 64-bit DMA addresses (f64_variant 2 / 3, and every problem beyond the scalar-base DMA's reach).
+static int resolve(const Problem &p) {
+  if (!mfma_f64_serves(p)) return -1;
   // scalar-base DMA: 32-bit byte offsets inside a tile's rows (256 rows x K x 8 B, 16 k-rows x M x 8 B) and K >= BK
   const bool sdma_fits = p.k >= 16 && 256ull * (p.a_transposed ? 1ull : p.k) * 8ull < (1ull << 32) &&
                          16ull * (p.m > p.n ? p.m : p.n) * 8ull < (1ull << 32);
-  if (tuning(TUNE_F64_VARIANT) >= 2 || !sdma_fits) return mfma_f64_tile(p) == 1 ? launch_d<D1R1>(s, p) : launch_d<D0R1>(s, p);
-  return mfma_f64_tile(p) == 1 ? launch_d<D1>(s, p) : launch_d<D0>(s, p);
+  return mfma_f64_tile(p) | ((tuning(TUNE_F64_VARIANT) >= 2 || !sdma_fits) ? 2 : 0);
+}
+
+const char *mfma_f64_name(const Problem &p) {
+  static const char *const names[] = {"mfma_f64_256x128x16_w8", "mfma_f64_128x128x16_w4x2", "mfma_f64_256x128x16_w8_compiler_placed",
+                                      "mfma_f64_128x128x16_w4x2_compiler_placed"};
+  const int r = resolve(p);
+  return r < 0 ? "unsupported" : names[r];
+}
+
+int launch_mfma_f64(hipStream_t s, const Problem &p) {
+  switch (resolve(p)) {
+    case 0: return launch_d<D0>(s, p);
+    case 1: return launch_d<D1>(s, p);
+    case 2: return launch_d<D0R1>(s, p);
+    case 3: return launch_d<D1R1>(s, p);
+  }
+  return kErrNotSupported;
 }
 
 }  // namespace mm

@@ -28,15 +28,39 @@ def test_cpu_baseline_object_shape():
         assert info["value"] and info["value"] > 0
 
 
-def test_traffic_comes_from_committed_profile():
+def test_replayed_counters_only_come_from_files_that_name_the_dispatched_kernel(tmp_path, monkeypatch):
+    """the traffic figure used to be picked by file-name sort, whatever kernel the file had profiled.
+    Now a committed PMC file is replayed only if its `kernel_name` and shape are the run's."""
     b = _bench()
-    t, source = b.hbm_traffic_per_launch()
-    assert t is None or t > 3.2e9  # never below the compulsory bytes of fp32 16384^3
-    assert t is None or (source.startswith("profiles/") and os.path.exists(os.path.join(ROOT, source)))
-    files = [f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_traffic.json")]
-    assert files, "profiles/*_traffic.json missing"
-    r = json.load(open(os.path.join(ROOT, "profiles", sorted(files)[-1])))
-    assert abs(r["write_bytes"] / r["c_bytes_exact"] - round(r["write_bytes"] / r["c_bytes_exact"])) < 1e-6
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    json.dump({"kernel_name": "mfma_f32_256x256x16_w8_flush4096", "shape": [16384] * 3, "hbm_bytes_per_launch": 37.6e9},
+              open(prof / "r09_traffic_other_kernel.json", "w"))
+    json.dump({"kernel_name": "mfma_f32_128x256x16_w4x2_flush4096", "shape": [16384] * 3, "hbm_bytes_per_launch": 51.8e9},
+              open(prof / "r03_traffic.json", "w"))
+    json.dump({"kernel_name": "mfma_f32_128x256x16_w4x2_flush4096", "size": 16384, "MfmaUtil_pct": 97.8,
+               "effective_clock_GHz_profiled": 2.37, "L2_hit_rate": 0.5}, open(prof / "r03_pmc.json", "w"))
+    json.dump({"kernel_name": "mfma_f32_128x256x16_w4x2_flush4096", "shape": [8192] * 3, "hbm_bytes_per_launch": 1.0},
+              open(prof / "r10_traffic_other_shape.json", "w"))
+    monkeypatch.setattr(b, "ROOT", str(tmp_path))
+    rc = b.replayed_counters("mfma_f32_128x256x16_w4x2_flush4096", (16384, 16384, 16384))
+    assert rc["traffic"] == 51.8e9 and rc["traffic_source"] == "profiles/r03_traffic.json"
+    assert rc["mfma_util_pct"] == 97.8 and rc["mfma_util_source"] == "profiles/r03_pmc.json"
+    assert b.replayed_counters("mfma_f32_128x128x32_w4x2_flush4096", (16384, 16384, 16384)) == {}
+    rl = b.attach_replayed({"avg_launch_ms": 58.0, "traffic": None}, "some_other_kernel", (16384, 16384, 16384))
+    assert rl["traffic"] is None and "not reported" in rl["traffic_note"]
+    rl = b.attach_replayed({"avg_launch_ms": 58.0, "traffic": None}, "mfma_f32_128x256x16_w4x2_flush4096", (16384,) * 3)
+    assert abs(rl["achieved_fabric_GBps"] - 51.8e9 / 58.0e-3 / 1e9) < 0.1 and "REPLAYED" in rl["traffic_note"]
+
+
+def test_committed_traffic_files_are_self_consistent():
+    files = [f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith(".json") and "traffic" in f]
+    assert files, "profiles/*traffic*.json missing"
+    for f in files:
+        r = json.load(open(os.path.join(ROOT, "profiles", f)))
+        assert r["hbm_bytes_per_launch"] > r["algorithmic_bytes_compulsory"]   # never below the compulsory bytes
+        if r.get("workload", "float") == "float" and "split" not in f:         # C written a whole number of times (flushes)
+            assert abs(r["write_bytes"] / r["c_bytes_exact"] - round(r["write_bytes"] / r["c_bytes_exact"])) < 1e-6, f
 
 
 def test_constants_match_baseline():

@@ -54,9 +54,17 @@ def test_kernel_name_dispatch_table():
     assert g.kernel_name(g.make_config("float", "Add", "Min"), 64, 64, 64) == "valu_tile"
     assert g.kernel_name(g.make_config("float", "Add", "Min"), 64, 63, 64) == "ordered"      # K % 4 != 0
     assert g.kernel_name(g.make_config("int", "And", "Add"), 64, 64, 64) == "ordered"        # And map
-    assert g.kernel_name(g.make_config("uint8_t"), 512, 512, 512) == "mfma_i8"
-    assert g.kernel_name(g.make_config("double"), 512, 512, 512) == "mfma_f64"
-    assert g.kernel_name(g.make_config("half"), 512, 512, 512) == "mfma_f16"
+    # every family names the kernel its launcher resolves to (one resolver per family, shared with the launch path)
+    assert g.kernel_name(g.make_config("uint8_t"), 512, 512, 512) == "mfma_i8_256x256_pingpong_16x16x64"
+    assert g.kernel_name(g.make_config("uint8_t"), 512, 576, 512) == "mfma_i8_256x256_pingpong_k64"
+    assert g.kernel_name(g.make_config("uint8_t"), 512, 96, 512) == "mfma_i8_256x256x128_slab128"
+    assert g.kernel_name(g.make_config("double"), 512, 512, 512).startswith("mfma_f64_128x128x16")
+    assert g.kernel_name(g.make_config("double"), 16384, 16384, 16384) == "mfma_f64_256x128x16_w8"
+    assert g.kernel_name(g.make_config("half"), 512, 512, 512) == "mfma_f16_128x256x64_slab64"     # small problem: 128-row tile
+    assert g.kernel_name(g.make_config("half"), 32768, 32768, 32768) == "mfma_f16_256x256_pingpong_16x16x32"
+    assert g.kernel_name(g.make_config("half"), 4096, 4128, 4096) == "mfma_f16_256x256_pingpong_k32"   # K % 64 != 0
+    assert g.kernel_name(g.make_config("half"), 4096, 4112, 4096) == "mfma_f16_256x256x64_slab64"      # K % 32 != 0
+    assert g.kernel_name(g.make_config("half", transposed_a=True), 4096, 4096, 4096) == "mfma_f16_256x256_pingpong_k32_KxN"
     assert g.kernel_name(g.make_config("float", transposed_a=True), 512, 512, 512).startswith("mfma_f32")
 
 
@@ -81,7 +89,7 @@ def test_bad_arguments_are_rejected_before_touching_a_device():
 
 def test_half_auto_path_never_falls_back_to_half_accumulation():
     """K % 16 != 0 (or M % 8 != 0) must not silently change half (x,+) semantics."""
-    assert g.kernel_name(g.make_config("half"), 512, 4096, 512) == "mfma_f16"
+    assert g.kernel_name(g.make_config("half"), 512, 4096, 512).startswith("mfma_f16_")
     assert g.kernel_name(g.make_config("half"), 512, 4104, 512) == "ordered_wide_f16"
     assert g.kernel_name(g.make_config("half"), 512, 4096, 516) == "ordered_wide_f16"
     assert g.kernel_name(g.make_config("half", path=g.PATH_ORDERED), 512, 4104, 512) == "ordered"
@@ -108,9 +116,23 @@ def test_tuning_environment_is_read_at_first_use():
     import sys
     code = ("import gemm_hls_amd as g; print(g.get_tuning('f32_variant'), g.get_tuning('band_rows'), "
             "g.kernel_name(g.make_config('float'), 4096, 4096, 4096))")
-    env = dict(os.environ, MM_F32_VARIANT="13", MM_BAND_ROWS="8", PYTHONPATH=ROOT)
+    env = dict(os.environ, MM_F32_VARIANT="35", MM_BAND_ROWS="8", PYTHONPATH=ROOT)
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout.split()
-    assert out == ["13", "8", "mfma_f32_128x256x32_w4_flush4096"]
+    assert out == ["35", "8", "mfma_f32_128x128x32_w4x2_flush4096"]
+
+
+def test_f32_variant_ids_of_the_product():
+    """The library holds five fp32 geometries: the three MM_PATH_AUTO picks from and two cross-check ones; every other
+    id (the lab's) names nothing here.  tests/test_gpu_parity.py iterates over exactly this list."""
+    valid = []
+    try:
+        for v in range(0, 64):
+            g.set_tuning("f32_variant", v)
+            if g.kernel_name(g.make_config("float"), 4096, 4096, 4096) != "unsupported":
+                valid.append(v)
+    finally:
+        g.set_tuning("f32_variant", -1)
+    assert valid == [0, 3, 8, 33, 35]
 
 
 def test_kernel_info_binding():

@@ -73,7 +73,7 @@ def test_double_16384_sampled_rows_and_properties():
     n = k = m = 16384
     a = _device_fill("double", (n, k), 41)
     b = _device_fill("double", (k, m), 42)
-    assert g.kernel_name(g.make_config("double"), n, k, m) == "mfma_f64"
+    assert g.kernel_name(g.make_config("double"), n, k, m) == "mfma_f64_256x128x16_w8"
     c = g.matmul(a, b, "double")
     torch.cuda.synchronize()
     rows, cols = _sample(n, m)
@@ -108,7 +108,7 @@ def test_half_32768_finite_inputs_sampled_rows_and_properties():
     b = _device_fill("half", (k, m), 52)
     a.mul_(2.0 ** -6)
     b.mul_(2.0 ** -6)
-    assert g.kernel_name(g.make_config("half"), n, k, m) == "mfma_f16"
+    assert g.kernel_name(g.make_config("half"), n, k, m) == "mfma_f16_256x256_pingpong_16x16x32"
     c = g.matmul(a, b, "half")
     torch.cuda.synchronize()
     assert bool(torch.isfinite(c).all())
@@ -245,7 +245,7 @@ def test_uint8_32768_bit_exact_against_ordered_kernel_and_naive():
     g0.manual_seed(91)
     a = torch.randint(0, 256, (n, k), dtype=torch.int16, device=dev, generator=g0).to(torch.uint8)
     b = torch.randint(0, 256, (k, m), dtype=torch.int16, device=dev, generator=g0).to(torch.uint8)
-    assert g.kernel_name(g.make_config("uint8_t"), n, k, m) == "mfma_i8"
+    assert g.kernel_name(g.make_config("uint8_t"), n, k, m) == "mfma_i8_256x256_pingpong_16x16x64"
     c = g.matmul(a, b, "uint8_t")
     torch.cuda.synchronize()
     rows, cols = _sample(n, m)

@@ -167,7 +167,7 @@ def test_tuning_set_switches_geometry_in_process():
     a, b = _oracle.fill("float", n, k, m)
     exact = a.astype(np.float64) @ b.astype(np.float64)
     try:
-        for v in (3, 13, 14):
+        for v in (3, 0, 35):
             g.set_tuning("f32_variant", v)
             assert g.get_tuning("f32_variant") == v
             c, _ = g.matmul_capi(a, b)
@@ -288,24 +288,66 @@ def test_library_loaded_before_torch_still_sees_the_gpu():
     assert r.returncode == 0 and "smoke ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
-def test_ablation_variants_are_refused_unless_unlocked():
-    """f16_variant 27 / 43 / 59 / 75 skip the DMA or the fragment reads on purpose (power breakdown,
-    DESIGN.md 3.2) and return wrong results: the library refuses them unless "ablations" is set."""
+def test_lab_variant_ids_are_not_in_the_product():
+    """The retired schedules and the work-skipping ablations (f16_variant 27 / 43 / 59 / 75: no DMA / no fragment reads /
+    L2-resident sources, wrong results on purpose; 300: the 384 x 256 tile; f32_variant 28-32; split 16 / 32) are
+    built into tools/lab/libmm_gemm_amd_lab.so only.  The product refuses their ids -- whatever "ablations" says --
+    instead of running something else under that name."""
     n = k = m = 512
     a = np.ones((n, k), np.float16)
     b = np.ones((k, m), np.float16)
     try:
-        for v in (27, 43, 59, 75):
-            g.set_tuning("f16_variant", v)
-            with pytest.raises(g.MMError):
-                g.matmul_capi(a, b, "half")
-        g.set_tuning("ablations", 1)
-        g.set_tuning("f16_variant", 75)      # L2-resident sources: runs, result is not the product
-        c, _ = g.matmul_capi(a, b, "half")
-        assert c.shape == (n, m)
+        for unlocked in (-1, 1):
+            g.set_tuning("ablations", unlocked)
+            for v in (27, 43, 59, 75, 300, 13):
+                g.set_tuning("f16_variant", v)
+                with pytest.raises(g.MMError):
+                    g.matmul_capi(a, b, "half")
+            g.set_tuning("f16_variant", -1)
+            for v in (28, 29, 30, 31, 32, 20, 13):
+                g.set_tuning("f32_variant", v)
+                with pytest.raises(g.MMError):
+                    g.matmul_capi(a.astype(np.float32), b.astype(np.float32))
+            g.set_tuning("f32_variant", -1)
+            for v in (16, 32):
+                g.set_tuning("split_variant", v)
+                with pytest.raises(g.MMError):
+                    g.matmul_capi(a.astype(np.float32), b.astype(np.float32), path=g.PATH_SPLIT)
+            g.set_tuning("split_variant", -1)
     finally:
-        g.set_tuning("ablations", -1)
-        g.set_tuning("f16_variant", -1)
+        for knob in ("ablations", "f16_variant", "f32_variant", "split_variant"):
+            g.set_tuning(knob, -1)
+
+
+def test_lab_library_runs_the_retired_schedules_and_gates_its_ablations():
+    """tools/lab/libmm_gemm_amd_lab.so (MM_LIB=lab for the measurement tools): same C ABI, the lab editions of the
+    matrix-core kernels.  Retired schedules still compute the product; ablations need MM_ABLATIONS=1."""
+    code = (
+        "import os, sys, numpy as np\n"
+        f"sys.path.insert(0, {os.path.join(ROOT, 'tools')!r})\n"
+        "from _lib import g\n"
+        "assert g.LIB_PATH.endswith('libmm_gemm_amd_lab.so')\n"
+        "rng = np.random.default_rng(3)\n"
+        "a = rng.uniform(1, 2, (300, 512)).astype(np.float32); b = rng.uniform(1, 2, (512, 272)).astype(np.float32)\n"
+        "exact = a.astype(np.float64) @ b.astype(np.float64)\n"
+        "for v in (1, 13, 20, 24, 34):\n"
+        "    g.set_tuning('f32_variant', v); c, _ = g.matmul_capi(a, b)\n"
+        "    assert np.max(np.abs(c - exact) / exact) < 1e-5, v\n"
+        "g.set_tuning('f32_variant', 29)\n"
+        "try:\n"
+        "    g.matmul_capi(a, b); raise SystemExit('ablation ran without MM_ABLATIONS')\n"
+        "except g.MMError: pass\n"
+        "g.set_tuning('ablations', 1); c, _ = g.matmul_capi(a, b); assert c.shape == (300, 272)\n"
+        "g.set_tuning('ablations', -1); g.set_tuning('f32_variant', -1)\n"
+        "ah, bh = a.astype(np.float16), b.astype(np.float16)\n"
+        "eh = ah.astype(np.float64) @ bh.astype(np.float64)\n"
+        "for v in (10, 13, 300, 302):\n"
+        "    g.set_tuning('f16_variant', v); c, _ = g.matmul_capi(ah, bh, 'half')\n"
+        "    assert np.max(np.abs(c.astype(np.float64) - eh) / eh) < 2.0 ** -10, v\n"
+        "print('lab ok')\n")
+    env = dict(os.environ, MM_LIB="lab")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0 and "lab ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 @pytest.mark.parametrize("path_name", ["auto", "split"])

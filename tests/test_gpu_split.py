@@ -206,24 +206,35 @@ def test_split_through_the_multi_device_driver():
 
 
 def test_release_workspace_returns_the_pool_memory_and_the_path_keeps_working():
+    """The packed planes come from a memory pool the LIBRARY owns (it used to raise the release threshold of the
+    process's default pool): freed workspace stays cached there between launches, the application's default pool is
+    never touched, and mm_release_workspace hands the cache back to the driver."""
     import torch
     hip = ctypes.CDLL("libamdhip64.so")   # the runtime this process already uses
 
-    def reserved_mib():
-        pool, v = ctypes.c_void_p(), ctypes.c_uint64(0)
+    def default_pool_state():
+        pool, reserved, threshold = ctypes.c_void_p(), ctypes.c_uint64(0), ctypes.c_uint64(0)
         assert hip.hipDeviceGetDefaultMemPool(ctypes.byref(pool), 0) == 0
-        assert hip.hipMemPoolGetAttribute(pool, 5, ctypes.byref(v)) == 0   # hipMemPoolAttrReservedMemCurrent
-        return v.value >> 20
+        assert hip.hipMemPoolGetAttribute(pool, 5, ctypes.byref(reserved)) == 0    # hipMemPoolAttrReservedMemCurrent
+        assert hip.hipMemPoolGetAttribute(pool, 4, ctypes.byref(threshold)) == 0   # hipMemPoolAttrReleaseThreshold
+        return reserved.value, threshold.value
 
     n = 2048
     a, b = _oracle.fill("float", n, 256, n)
     c0, _ = g.matmul_capi(a, b, path=g.PATH_SPLIT)
-    big = torch.empty((8192, 8192), dtype=torch.float32, device="cuda").uniform_(1, 10)
-    g.matmul(big, big, path=g.PATH_SPLIT)          # 2 x 8192^2 x 6 B = 768 MiB of workspace now sit in the pool
-    torch.cuda.synchronize()
-    assert reserved_mib() >= 768
     g._check(g.lib().mm_release_workspace(0))
-    assert reserved_mib() == 0
+    big = torch.empty((8192, 8192), dtype=torch.float32, device="cuda").uniform_(1, 10)
+    out = torch.empty_like(big)
+    torch.cuda.synchronize()
+    before = default_pool_state()
+    free_before = torch.cuda.mem_get_info()[0]
+    g.matmul(big, big, path=g.PATH_SPLIT, out=out)  # 2 x 8192^2 x 6 B = 768 MiB of workspace now sit in the library's pool
+    torch.cuda.synchronize()
+    assert free_before - torch.cuda.mem_get_info()[0] >= 760 << 20
+    assert default_pool_state() == before            # not in the application's pool, and its threshold is as it was
+    g._check(g.lib().mm_release_workspace(0))
+    assert free_before - torch.cuda.mem_get_info()[0] <= 32 << 20
+    assert default_pool_state() == before
     c1, _ = g.matmul_capi(a, b, path=g.PATH_SPLIT)
     assert np.array_equal(c0, c1)
     with pytest.raises(g.MMError):

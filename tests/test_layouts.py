@@ -310,3 +310,83 @@ def test_valu_tile_dma_a_pairs_roundtrip_and_banks():
             assert lc * 4 + (a % 16) // 4 == kk                        # first element of the pair is k = kk
         b64_half_banks_disjoint(addr, range(0, 32))
         b64_half_banks_disjoint(addr, range(32, 64))
+
+
+# ---------------------------------------------------------------- 16 x 16 matrix instructions (round 3) ------------
+def test_pingpong_16x16_a_operand_on_full_line_rows_roundtrip_and_banks():
+    """mfma_f16_pp2s_kernel / mfma_i8_pp2s_kernel: the A double slab of the full-line kernels, unchanged
+    ([256 rows][128 B], source chunk = pc ^ ((row>>1)&7)), read for the 16x16x32 (16x16x64) operand: lane l takes row
+    l&15 of a 16-row block and the 16-byte chunk 4*H + (l>>4) (H = slab parity inside the double slab)."""
+    lds = {}
+    for piece in range(32):
+        for lane in range(64):
+            row, pc = piece * 8 + lane // 8, lane % 8
+            lds[piece * 1024 + lane * 16] = (row, pc ^ ((row >> 1) & 7))
+    for wm, rb, H in itertools.product(range(2), range(8), range(2)):
+        def addr(l):
+            l15, g = l & 15, l >> 4
+            return (wm * 128 + l15) * 128 + ((4 * H + g) ^ (l15 >> 1)) * 16 + rb * 16 * 128
+        for l in range(64):
+            row, lc = lds[addr(l)]
+            assert row == wm * 128 + rb * 16 + (l & 15) and lc == 4 * H + (l >> 4)   # k = 32*H + 8*(l>>4) .. +7 (halves)
+        assert_conflict_free_b128(addr)
+
+
+def test_pingpong_16x16x32_f16_b_image_roundtrip_and_banks():
+    """B slab [32 k][256 cols] halves for the 16x16x32 operand: the two 16-lane groups of a half-wave differ in k by 8
+    (not in column by 16), so the source chunk is pb ^ ((k&3)<<2) ^ (((k>>3)&1)<<1); lane group g = l>>4 gathers
+    k = 8g .. 8g+7 of 16 columns with two transpose reads."""
+    BROW = 512
+    lds = {}
+    for piece in range(16):
+        for lane in range(64):
+            kr, pb = piece * 2 + lane // 32, lane % 32
+            lds[piece * 1024 + lane * 16] = (kr, pb ^ ((kr & 3) << 2) ^ (((kr >> 3) & 1) << 1))
+
+    def element_at(byte_addr):
+        base = (byte_addr // 16) * 16
+        kr, lc = lds[base]
+        return kr, lc * 8 + (byte_addr - base) // 2
+
+    for h2, nb, wn in itertools.product(range(2), range(4), range(4)):
+        def addr(l):
+            l15, g = l & 15, l >> 4
+            r, piece = l15 >> 2, l15 & 3
+            logical = wn * 8 + nb * 2 + (piece >> 1)
+            return (8 * g + r) * BROW + (logical ^ (r << 2) ^ ((g & 1) << 1)) * 16 + (piece & 1) * 8 + h2 * 4 * BROW
+        for l in range(64):
+            i, grp = l & 15, l & ~15
+            for j in range(4):   # hardware transpose: out[i][j] = in[4j + (i>>2)][i&3]
+                k, col = element_at(addr(grp + 4 * j + (i >> 2)) + 2 * (i & 3))
+                assert k == 8 * (l >> 4) + 4 * h2 + j and col == wn * 64 + nb * 16 + (l & 15)
+        b64_half_banks_disjoint(addr, range(0, 32))
+        b64_half_banks_disjoint(addr, range(32, 64))
+
+
+def test_pingpong_16x16x64_i8_b_image_roundtrip_and_banks():
+    """B slab [64 k][256 cols] bytes for the 16x16x64 operand: source chunk = pb ^ (((k&7)<<1) | ((k>>4)&1)); lane group
+    g gathers k = 16g .. 16g+15 of 16 columns with two 8-bit transpose reads."""
+    BROW = 256
+    lds = {}
+    for piece in range(16):
+        for lane in range(64):
+            kr, pb = piece * 4 + lane // 16, lane % 16
+            lds[piece * 1024 + lane * 16] = (kr, pb ^ (((kr & 7) << 1) | ((kr >> 4) & 1)))
+
+    def element_at(byte_addr):
+        base = (byte_addr // 16) * 16
+        kr, lc = lds[base]
+        return kr, lc * 16 + (byte_addr - base)
+
+    for h2, nb, wn in itertools.product(range(2), range(4), range(4)):
+        def addr(l):
+            l15, g = l & 15, l >> 4
+            r, q = l15 >> 1, l15 & 1
+            return (16 * g + r) * BROW + 8 * q + ((wn * 4 + nb) ^ ((r << 1) | (g & 1))) * 16 + h2 * 8 * BROW
+        for l in range(64):
+            i, grp = l & 15, l & ~15
+            for j in range(8):   # out[i][j] = in[2j + (i>>3)][i&7]
+                k, col = element_at(addr(grp + 2 * j + (i >> 3)) + (i & 7))
+                assert k == 16 * (l >> 4) + 8 * h2 + j and col == wn * 64 + nb * 16 + (l & 15)
+        b64_half_banks_disjoint(addr, range(0, 32))
+        b64_half_banks_disjoint(addr, range(32, 64))

@@ -9,7 +9,8 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
-import gemm_hls_amd as g  # noqa: E402
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _lib import g  # noqa: E402  (MM_LIB=lab selects the lab build)
 
 for dtype, tdt, n in (("half", torch.float16, 16384), ("float", torch.float32, 16384)):
     dev = torch.device("cuda:0")

@@ -1,23 +1,20 @@
+// LAB EDITION (tools/lab, built into libmm_gemm_amd_lab.so only): the schedules, cache-policy experiments, tile shapes
+// and ablations (some return WRONG results on purpose; they need MM_ABLATIONS=1) behind the numbers under profiles/.
+// The product file is gemm_hls_amd/csrc/mm_mfma_f16.hip.
+//
 // half (Multiply, Add) fast path for gfx950: C[N x M] = A[N x K] . B[K x M], row-major binary16
-// in and out, on the f16 matrix-core instructions (v_mfma_f32_16x16x32_f16 / v_mfma_f32_32x32x16_f16).
+// in and out, on v_mfma_f32_32x32x16_f16.
 //
 // Numerical contract: products of two binary16 values are exact in f32;
 // they are accumulated in f32 by the matrix core and rounded to binary16 ONCE on store.  The
 // reference's HLS kernel accumulates in half (and overflows to inf beyond K ~ 2000 on its own
 // [1,10) inputs); the k-ordered kernel (MM_PATH_ORDERED) reproduces that behaviour exactly.
 //
-// Kernels in this file (what MM_PATH_AUTO can dispatch, plus one cross-check):
-//   pingpong_16x16x32   default: 256 x 256 tile, ping-pong schedule, A in full-line double slabs, the 16x16x32
-//                       instruction (K % 64 == 0, K >= 256, row-major A)
-//   pingpong_32x32x16   the same tile / rings / protocol on the 32x32x16 instruction: the independently written
-//                       cross-check of the default (f16_variant 100); also what round 2 shipped
-//   pingpong_k32        32-deep slabs with 64-byte A rows (K % 32 == 0, K >= 128), row-major and K x N A
-//   slab64              one barrier per 64-deep slab (K % 16 == 0; any N; 256 x 256, or 128 x 256 for small problems)
-// The schedules and ablations these went through (lock step, early barrier, DMA cache policies, no-DMA / no-read power
-// breakdown, the 384 x 256 tile) live in tools/lab/lab_mfma_f16.hip -> tools/lab/libmm_gemm_amd_lab.so.
-//
-// Common organisation (as mm_mfma_f32.hip: resident output tile, LDS ring fed by global_load_lds):
-//   B fragment: B is K x M row-major, the operand wants consecutive k of ONE column, so the
+// Organisation as in mm_mfma_f32.hip (resident output tile, LDS ring fed by global_load_lds):
+//   workgroup 256 x 256, 8 wavefronts as 4 x 2, each 64 x 128 = 2 x 4 accumulators of 32 x 32;
+//   K slab = 64 halves (an A row is 128 B = 8 chunks of 16 B, swizzled with (row>>1)&7);
+//   A fragment: ds_read_b128 = A[row = l&31][8 consecutive k at 8*(l>>5)] -- exactly the operand;
+//   B fragment: B is K x M row-major, the operand wants 8 consecutive k of ONE column, so the
 //     LDS image stays row-major [k][256 cols] and the operand is gathered by two
 //     ds_read_b64_tr_b16 (hardware 4 x 16 transpose: lane i of a 16-lane group receives column i
 //     of the [4 k][16 col] block whose rows the group's lanes point at;
@@ -29,7 +26,7 @@
 #include <cstdlib>
 #include <type_traits>
 
-#include "mm_common.h"
+#include "../../gemm_hls_amd/csrc/mm_common.h"
 
 namespace mm {
 namespace {
@@ -62,10 +59,10 @@ struct GeoHT {
   static_assert(LDS_BYTES <= 160 * 1024, "LDS");
   static_assert(BN == 256, "B swizzle / chunk math assumes 256-column slabs");
 };
-// slab64: workgroup 256 x 256 (or 128 x 256), wavefronts of 64 x 128 = 2 x 4 accumulators of 32 x 32 (32x32x16 instruction);
-// K slab = 64 halves (an A row is 128 B = 8 chunks of 16 B, swizzled with (row>>1)&7); A fragment: ds_read_b128 =
-// A[row = l&31][8 consecutive k at 8*(l>>5)] -- exactly the operand; one barrier per slab, fragments double-buffered.
 using GeoH = GeoHT<4, 2, 2>;   // 256 x 256, 8 wavefronts of 64 x 128 (2 per SIMD)
+using GeoH4 = GeoHT<2, 2, 4>;  // 256 x 256, 4 wavefronts of 128 x 128 (1 per SIMD, 256 accumulators)
+using GeoH32x4 = GeoHT<4, 2, 2, 32, 4>;  // 32-deep slabs, 4-slab ring: 3 slabs (96 KiB) in flight
+using GeoH32x3 = GeoHT<4, 2, 2, 32, 3>;  // 32-deep slabs, 3-slab ring
 using GeoHS = GeoHT<2, 2, 2>;            // 128 x 256, 4 wavefronts of 64 x 128: small / mid-size shapes
 
 // LDS-DMA issued from inline asm.  hipcc waits vmcnt(0) before every ds_read_b64_tr_b16 that
@@ -284,30 +281,31 @@ __global__ __launch_bounds__(G::THREADS) void mfma_f16_kernel(const _Float16 *__
 
 
 // =================================================================================================
-// Ping-pong schedule (round 2): the 256 x 256 resident tile, organised so that the matrix pipe
+// Ping-pong kernel (round 2): the same 256 x 256 resident tile, rescheduled so that the matrix pipe
 // of every SIMD is fed by ONE of its two waves at a time while the other one does all of its memory
-// work.  Why: with both waves of a SIMD in the same phase, each LDS-DMA instruction blocks its wave's
-// in-order issue for 60-190 cycles (MI355X_MICROARCH.md: "LDS-DMA piece issue cost"), so right after every
-// slab barrier all 8 waves sit in their DMA issue and the matrix pipes idle (ablation: no refill = +31 %).  Here
-//   * k-slabs are 32 deep, 4-slab LDS ring (4 x 32 KiB), 3 slabs in flight;
+// work.  Why: in the kernel above both waves of a SIMD run the same phase at the same time; each
+// LDS-DMA instruction blocks its wave's in-order issue for 60-190 cycles (MI355X_MICROARCH.md
+// constants: "LDS-DMA piece issue cost"), so right after every slab barrier all 8 waves sit in their
+// DMA issue and the matrix pipes idle (ablation: no refill = +31 %).  Here
+//   * k-slabs are 32 deep (2 MFMA k-steps), 4-slab LDS ring (4 x 32 KiB), 3 slabs in flight;
 //   * waves 0-3 (one per SIMD) and waves 4-7 (their SIMD partners) run the same code shifted by one
-//     barrier: while group X executes the MFMAs of slab u ("compute segment", priority 1),
+//     barrier: while group X executes its 16 MFMAs of slab u ("compute segment", priority 1),
 //     group Y reads its fragments of its next slab from LDS and issues its 4 DMA pieces of a slab
 //     three ahead ("load segment"); one s_barrier per segment keeps the two groups in antiphase;
-//   * 8 waves as 2 x 4, 128 x 64 per wave; fragments single-buffered (load and compute segments of
+//   * 8 waves as 2 x 4, 128 x 64 per wave = 4 x 2 accumulators: per slab 8 ds_read_b128 (A) + 8
+//     ds_read_b64_tr_b16 (B) for 16 MFMAs, fragments single-buffered (load and compute segments of
 //     one wave never overlap -- the overlap comes from the partner wave);
 //   * DMA sources are (uniform SGPR base) + (32-bit per-lane offset): the per-lane part never
 //     changes, the base advances by one slab per segment with scalar adds: no vector address math
 //     in the loop.
 // LDS-DMA hand-over rules (cdna_hip_programming.md, 8-phase template): a slab is read one segment
 // AFTER the counted vmcnt + barrier that retires it; a buffer is refilled only after a barrier that
-// every reader passed with lgkmcnt(0) (replayed on the CPU by tests/test_schedules.py).
-//
-// pingpong_k32: 32-deep slabs for A and B (K % 32 == 0, the reference's own contract for half: 64-byte bus = 32
-// elements, host/RunHardware.cpp:50-55), on the 32x32x16 instruction; row-major A or K x N A (staged and gathered like B).
+// every reader passed with lgkmcnt(0).
 //   A slab image [256 rows][32 k]: 64-B rows, 16-B chunk index XORed with (row>>2)&3 (a
 //   ds_read_b128 lane group = 16 rows x 16 B must cover all 16 slots of the 256-B bank row);
-//   B slab image [32 k][256 cols]: chunk index ^ (k&3)<<2.
+//   B slab image [32 k][256 cols]: as above (chunk index ^ (k&3)<<2).
+// Requirements: K % 32 == 0 (the reference's own contract for half: 64-byte bus = 32 elements,
+// host/RunHardware.cpp:50-55), M % 8 == 0, row-major A.  Other shapes: the kernel above.
 struct GeoPP {
   static constexpr int BM = 256, BN = 256, BK = 32, NS = 4, THREADS = 512;
   static constexpr int TM = 4, TN = 2;  // 128 x 64 per wave
@@ -319,7 +317,15 @@ struct GeoPP {
 // one LDS-DMA piece: 64 lanes x 16 B from (uniform base + per-lane 32-bit offset) to LDS at m0
 #define MM_DMA_PIECE(vo, sb, la) "s_mov_b32 m0, " la "\n\ts_nop 0\n\tglobal_load_lds_dwordx4 " vo ", " sb "\n\t"
 
-template <bool AT>  // AT: A stored K x N (MM_TRANSPOSED_A): the A slab is staged and gathered exactly like B's
+// VAR bit 0: s_setprio around the MFMA segment; bit 1: lock-step ablation (no antiphase);
+// bit 2: the barrier that ends a compute segment is executed 4 MFMAs early, so the partner's first
+//        MFMAs queue up behind this wave's last ones instead of behind a barrier round trip;
+// bit 3: DMA pieces issued before (instead of after) the fragment reads of a load segment.
+// Ablations for the power breakdown (WRONG results by construction, never dispatched by default):
+// bit 4: no DMA in the main loop; bit 5: no fragment reads in the main loop (the first slab's are reused);
+// bit 6: every workgroup streams tile (0, 0)'s panels (all DMA traffic becomes L2 hits: splits the
+//        CU-side cost of the DMA path from the fabric / HBM side).
+template <int VAR, bool AT = false>  // AT: A stored K x N (MM_TRANSPOSED_A): the A slab is staged and gathered exactly like B's
 __global__ __launch_bounds__(GeoPP::THREADS) void mfma_f16_pp_kernel(const _Float16 *__restrict__ A,
                                                                        const _Float16 *__restrict__ B,
                                                                        _Float16 *__restrict__ C, unsigned N, unsigned K,
@@ -354,8 +360,8 @@ __global__ __launch_bounds__(GeoPP::THREADS) void mfma_f16_pp_kernel(const _Floa
                    : (min(row0 + row, N - 1) - row0) * K * 2 + chunk * 16;
     voff_b[i] = kr * M * 2 + (min(col0 + lc * 8, M - 8) - col0) * 2;
   }
-  const char *a_base = (const char *)A + (AT ? (size_t)row0 * 2 : (size_t)row0 * K * 2);
-  const char *b_base = (const char *)B + (size_t)col0 * 2;
+  const char *a_base = (const char *)A + ((VAR & 64) ? 0 : AT ? (size_t)row0 * 2 : (size_t)row0 * K * 2);
+  const char *b_base = (const char *)B + ((VAR & 64) ? 0 : (size_t)col0 * 2);
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
   const unsigned U = K / G::BK;
   auto issue = [&](unsigned slab, unsigned buf) {
@@ -400,6 +406,7 @@ __global__ __launch_bounds__(GeoPP::THREADS) void mfma_f16_pp_kernel(const _Floa
 #pragma unroll
     for (int ni = 0; ni < TN; ++ni) acc[mi][ni] = (f32x16)0.0f;
 
+  h8 af_keep[TM][2], bf_keep[TN][2];  // ablation bit 5 only
   auto sync = [&]() {
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
@@ -408,8 +415,10 @@ __global__ __launch_bounds__(GeoPP::THREADS) void mfma_f16_pp_kernel(const _Floa
   // one slab: load segment | barrier | compute segment | barrier
   auto phase = [&](auto bufc, unsigned u) {
     constexpr int BUF = decltype(bufc)::value;
-    const char *base = smem + BUF * G::STAGE_BYTES;
+    const char *base = smem + ((VAR & 32) ? 0 : BUF) * G::STAGE_BYTES;
     h8 af[TM][2], bf[TN][2];
+    if ((VAR & 8) && !(VAR & 16)) issue(u + 3, (BUF + 3) & 3);
+    if (!(VAR & 32) || u == 0) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
@@ -431,19 +440,40 @@ __global__ __launch_bounds__(GeoPP::THREADS) void mfma_f16_pp_kernel(const _Floa
         }
       }
     }
-    issue(u + 3, (BUF + 3) & 3);
+    if (VAR & 32) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) af_keep[mi][ks] = af[mi][ks];
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) bf_keep[ni][ks] = bf[ni][ks];
+      }
+    }
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) af[mi][ks] = af_keep[mi][ks];
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) bf[ni][ks] = bf_keep[ni][ks];
+      }
+    }
+    if (!(VAR & 8) && !(VAR & 16)) issue(u + 3, (BUF + 3) & 3);
     asm volatile("s_waitcnt vmcnt(8)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");  // own pieces of slab u+1 landed; fragments in registers
     sync();
-    __builtin_amdgcn_s_setprio(1);
+    if (VAR & 1) __builtin_amdgcn_s_setprio(1);
+    constexpr int EARLY = (VAR & 4) ? 4 : 0;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < TN; ++ni)
+        for (int ni = 0; ni < TN; ++ni) {
+          if (EARLY && ks * 8 + mi * 2 + ni == 16 - EARLY) sync();
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mi][ks], bf[ni][ks], acc[mi][ni], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
-    sync();
+        }
+    if (VAR & 1) __builtin_amdgcn_s_setprio(0);
+    if (!EARLY) sync();
   };
 
   // ---- prologue: 3 slabs in flight, slab 0 published -------------------------------------------------
@@ -452,7 +482,7 @@ __global__ __launch_bounds__(GeoPP::THREADS) void mfma_f16_pp_kernel(const _Floa
   issue(2, 2);
   asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   sync();
-  const bool shifted = group == 1;
+  const bool shifted = !(VAR & 2) && group == 1;
   if (shifted) sync();                                   // group 1 runs one segment behind group 0
   for (unsigned u = 0; u < U; u += 4) {
     phase(std::integral_constant<int, 0>{}, u);
@@ -461,7 +491,7 @@ __global__ __launch_bounds__(GeoPP::THREADS) void mfma_f16_pp_kernel(const _Floa
     if (u + 3 < U) phase(std::integral_constant<int, 3>{}, u + 3);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // trailing (dead) refills must have landed before LDS is reused
-  if (!shifted) sync();                                  // group 0 waits for group 1's last segment
+  if (!shifted && !(VAR & 2)) sync();                    // group 0 waits for group 1's last segment
   sync();
 
   // ---- epilogue: one rounding f32 -> binary16, staged through this wave's 16 KiB slice of the ring
@@ -488,15 +518,15 @@ __global__ __launch_bounds__(GeoPP::THREADS) void mfma_f16_pp_kernel(const _Floa
 }
 
 // -------------------------------------------------------------------------------------------------
-// Ping-pong with full-line A requests.  A 32-deep slab gives A rows of 64 bytes, i.e. TWO L2 requests per 128-byte
-// line (one per slab); measured: 817 M vs 546 M L2 requests per 16384^3 launch at identical misses, on a kernel
+// Ping-pong kernel, full-line A requests ("pp2").  Same schedule as above; the difference is how A
+// travels.  A 32-deep slab gives A rows of 64 bytes, i.e. TWO L2 requests per 128-byte line (one per
+// slab); measured: 817 M vs 546 M L2 requests per 16384^3 launch at identical misses, on a kernel
 // whose power budget goes into exactly that path.  Here A is staged in DOUBLE slabs
 // [256 rows][64 k] (128-byte rows, one request per line, chunk index ^ (row>>1)&7), each double slab
 // serving two consecutive segments; B stays in 32-deep slabs.  LDS: 3 A double slabs (96 KiB) +
 // 4 B slabs (64 KiB) = all 160 KiB.  A wave still issues 4 DMA pieces per load segment: 2 of A
 // (its half of double slab u/2 + 2) and 2 of B (slab u + 3); the counted vmcnt(8) and the barrier
 // pairing are unchanged.  Requirements: K % 64 == 0, K >= 256.
-// pingpong_32x32x16: this organisation on v_mfma_f32_32x32x16_f16 (4 x 2 accumulators of 32 x 32 per wavefront).
 struct GeoPP2 {
   static constexpr int BM = 256, BN = 256, BK = 32, THREADS = 512;
   static constexpr int TM = 4, TN = 2;
@@ -507,6 +537,7 @@ struct GeoPP2 {
   static constexpr int BROW = BN * 2;
 };
 
+template <int VAR>  // bit 1: lock-step ablation
 __global__ __launch_bounds__(GeoPP2::THREADS) void mfma_f16_pp2_kernel(const _Float16 *__restrict__ A,
                                                                          const _Float16 *__restrict__ B,
                                                                          _Float16 *__restrict__ C, unsigned N, unsigned K,
@@ -544,24 +575,34 @@ __global__ __launch_bounds__(GeoPP2::THREADS) void mfma_f16_pp2_kernel(const _Fl
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
   const unsigned U = K / G::BK, UD = U / 2;
   // half `h` (pieces wave+16h, wave+16h+8) of A double slab `ds` into A buffer `abuf`, and B slab `slab` into B buffer `bbuf`
-#define MM_PP2_ISSUE(V0, V1, SB, L0, L1)                                                                   \
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3"       \
-               "\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0" \
-               : "=&s"(keep)                                                                               \
-               : "v"(V0), "v"(V1), "s"(SB), "s"(L0), "s"(L1)                                               \
+  // cache policy of the DMA loads (experiment knob): VAR bits 2-3 = A pieces, bits 4-5 = B pieces;
+  // 0 default, 1 "nt", 2 "sc1", 3 "sc0 sc1"
+#define MM_PP2_ISSUE(POL, V0, V1, SB, L0, L1)                                                                        \
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3" POL           \
+               "\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3" POL "\n\ts_mov_b32 m0, %0" \
+               : "=&s"(keep)                                                                                         \
+               : "v"(V0), "v"(V1), "s"(SB), "s"(L0), "s"(L1)                                                         \
                : "memory")
   auto issue_a = [&](unsigned ds, unsigned abuf, int h) {
     const char *ap = a_base + (size_t)min(ds, UD - 1) * 128;
     const unsigned la0 = lds0 + abuf * G::A2_BYTES + (wave + 16 * h) * 1024, la1 = la0 + 8 * 1024;
     const unsigned v0 = h ? voff_a[2] : voff_a[0], v1 = h ? voff_a[3] : voff_a[1];
     unsigned keep;
-    MM_PP2_ISSUE(v0, v1, ap, la0, la1);
+    constexpr int POL = (VAR >> 2) & 3;
+    if constexpr (POL == 0) MM_PP2_ISSUE("", v0, v1, ap, la0, la1);
+    else if constexpr (POL == 1) MM_PP2_ISSUE(" nt", v0, v1, ap, la0, la1);
+    else if constexpr (POL == 2) MM_PP2_ISSUE(" sc1", v0, v1, ap, la0, la1);
+    else MM_PP2_ISSUE(" sc0 sc1", v0, v1, ap, la0, la1);
   };
   auto issue_b = [&](unsigned slab, unsigned bbuf) {
     const char *bp = b_base + (size_t)min(slab, U - 1) * G::BK * M * 2;
     const unsigned lb0 = lds0 + G::B_REGION + bbuf * G::B_BYTES + wave * 1024, lb1 = lb0 + 8 * 1024;
     unsigned keep;
-    MM_PP2_ISSUE(voff_b[0], voff_b[1], bp, lb0, lb1);
+    constexpr int POL = (VAR >> 4) & 3;
+    if constexpr (POL == 0) MM_PP2_ISSUE("", voff_b[0], voff_b[1], bp, lb0, lb1);
+    else if constexpr (POL == 1) MM_PP2_ISSUE(" nt", voff_b[0], voff_b[1], bp, lb0, lb1);
+    else if constexpr (POL == 2) MM_PP2_ISSUE(" sc1", voff_b[0], voff_b[1], bp, lb0, lb1);
+    else MM_PP2_ISSUE(" sc0 sc1", voff_b[0], voff_b[1], bp, lb0, lb1);
   };
 #undef MM_PP2_ISSUE
 
@@ -638,7 +679,7 @@ __global__ __launch_bounds__(GeoPP2::THREADS) void mfma_f16_pp2_kernel(const _Fl
   issue_b(2, 2);
   asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   sync();
-  const bool shifted = group == 1;
+  const bool shifted = !(VAR & 2) && group == 1;
   if (shifted) sync();
   unsigned ab = 0;  // (u / 2) % 3 at the top of the 4-slab body
   for (unsigned u = 0; u < U; u += 4) {
@@ -652,7 +693,7 @@ __global__ __launch_bounds__(GeoPP2::THREADS) void mfma_f16_pp2_kernel(const _Fl
     ab = ab1 == 2 ? 0 : ab1 + 1;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (!shifted) sync();
+  if (!shifted && !(VAR & 2)) sync();
   sync();
 
   {
@@ -678,8 +719,8 @@ __global__ __launch_bounds__(GeoPP2::THREADS) void mfma_f16_pp2_kernel(const _Fl
 }
 
 // -------------------------------------------------------------------------------------------------
-// pingpong_16x16x32 (round 3, the default).  Same tile, LDS rings, DMA and segment
-// protocol as pingpong_32x32x16; what changes is the matrix instruction: 16 x 16 outputs x 32 k (4 accumulator
+// Ping-pong kernel on v_mfma_f32_16x16x32_f16 ("pp2s", round 3).  Same tile, LDS rings, DMA and segment
+// protocol as pp2; what changes is the matrix instruction: 16 x 16 outputs x 32 k (4 accumulator
 // registers, 16 cycles) instead of 32 x 32 x 16 (16 registers, 32 cycles).  Both run at the same flop rate,
 // but on random [1,10) operands the register-only loop of the 16x16x32 form holds 1.98 GHz = 2.06 PF where
 // the 32x32x16 form holds 1.68 GHz = 1.76 PF (tools/probes/probe_mfma_power.hip,
@@ -695,6 +736,7 @@ __global__ __launch_bounds__(GeoPP2::THREADS) void mfma_f16_pp2_kernel(const _Fl
 //     half-wave touches fall into 8 different 32-byte octants of the 256-byte bank row.
 // Accumulation order per output element: k ascending in steps of 32, inside an MFMA the hardware's order;
 // results are within the same 1-ulp-of-binary16 bound as the 32x32x16 kernels (not bit-identical to them).
+template <int VAR>  // bit 1: lock-step ablation
 __global__ __launch_bounds__(GeoPP2::THREADS) void mfma_f16_pp2s_kernel(const _Float16 *__restrict__ A,
                                                                           const _Float16 *__restrict__ B,
                                                                           _Float16 *__restrict__ C, unsigned N, unsigned K,
@@ -814,7 +856,7 @@ __global__ __launch_bounds__(GeoPP2::THREADS) void mfma_f16_pp2s_kernel(const _F
   issue_b(2, 2);
   asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   sync();
-  const bool shifted = group == 1;
+  const bool shifted = !(VAR & 2) && group == 1;
   if (shifted) sync();
   unsigned ab = 0;
   for (unsigned u = 0; u < U; u += 4) {
@@ -828,7 +870,7 @@ __global__ __launch_bounds__(GeoPP2::THREADS) void mfma_f16_pp2s_kernel(const _F
     ab = ab1 == 2 ? 0 : ab1 + 1;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (!shifted) sync();
+  if (!shifted && !(VAR & 2)) sync();
   sync();
 
   {  // epilogue: C/D of the 16x16 form: column l15, rows 4*g + i
@@ -851,13 +893,199 @@ __global__ __launch_bounds__(GeoPP2::THREADS) void mfma_f16_pp2s_kernel(const _F
   }
 }
 
-#undef MM_DMA_PIECE
+// -------------------------------------------------------------------------------------------------
+// 384 x 256 tile on the 16x16x32 instruction ("pp3", round 3).  The power breakdown of the 256 x 256 kernels says
+// the global -> LDS path is the largest consumer beside the matrix cores and its bytes per flop are fixed by the
+// tile: (BM + BN) / (BM * BN).  384 x 256 moves 16.7 % fewer bytes per flop through L2 -> LDS and, for the same
+// 4 x 8 arrangement of an XCD's 32 resident tiles, 22 % fewer through the fabric.  It fits because the 16-row
+// granularity of the 16x16x32 form allows a 96 x 128 wavefront part (6 x 8 accumulators = 192 registers):
+//   8 wavefronts as 4 x 2; SIMD partners (w, w + 4) side by side in N; ping-pong protocol as above;
+//   ring of 4 stages of [A 384 rows x 32 k (64-byte rows)] + [B 32 k x 256 cols] = 4 x 40 KiB = all of the LDS
+//   (three A double slabs of 128-byte rows would need 144 KiB: the full-line A requests of pp2 do not fit);
+//   a wavefront issues 5 DMA pieces per segment (3 of A, 2 of B) against 48 MFMAs; two slabs in flight, counted vmcnt(5).
+//   A image: 64-byte rows, chunk index ^ (-(row>>2))&3 -- with the 16x16 operand (row l&15, chunk l>>4) each
+//   ds_read_b128 service group covers 16 distinct slots (tests/test_layouts.py); B image as pp2s.
+// Requirements: K % 32 == 0, K >= 128, M % 8 == 0, row-major A.
+struct GeoPP3 {
+  static constexpr int BM = 384, BN = 256, BK = 32, NS = 4, THREADS = 512;
+  static constexpr int RB = 6, NB = 8;  // 96 x 128 per wavefront
+  static constexpr int A_BYTES = BM * BK * 2, B_BYTES = BK * BN * 2, STAGE_BYTES = A_BYTES + B_BYTES;  // 24 + 16 KiB
+  static constexpr int LDS_BYTES = NS * STAGE_BYTES;  // 163840
+  static constexpr int BROW = BN * 2;
+};
 
-enum Kind { K_PP16, K_PP32, K_PPK32, K_PPK32_AT, K_SLAB64, K_SLAB64_AT, K_SLAB64_128, K_NONE };
-const char *const kNames[] = {"mfma_f16_256x256_pingpong_16x16x32", "mfma_f16_256x256_pingpong_32x32x16",
-                              "mfma_f16_256x256_pingpong_k32", "mfma_f16_256x256_pingpong_k32_KxN",
-                              "mfma_f16_256x256x64_slab64", "mfma_f16_256x256x64_slab64_KxN", "mfma_f16_128x256x64_slab64",
-                              "unsupported"};
+template <int VAR>
+__global__ __launch_bounds__(GeoPP3::THREADS) void mfma_f16_pp3_kernel(const _Float16 *__restrict__ A,
+                                                                         const _Float16 *__restrict__ B,
+                                                                         _Float16 *__restrict__ C, unsigned N, unsigned K,
+                                                                         unsigned M, unsigned tiles_n, unsigned tiles_m,
+                                                                         unsigned kBand) {
+  using G = GeoPP3;
+  constexpr int RB = G::RB, NB = G::NB;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const unsigned lane = threadIdx.x & 63u;
+  const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const unsigned group = wave >> 2, wm = wave & 3u, wn = group;   // waves w and w + 4 share a SIMD
+  const unsigned l15 = lane & 15u, g = lane >> 4;
+
+  const unsigned lin = xcd_remap(blockIdx.x, tiles_n * tiles_m);
+  const unsigned band = lin / (kBand * tiles_m), within = lin % (kBand * tiles_m);
+  const unsigned rows_in_band = min(kBand, tiles_n - band * kBand);
+  const unsigned row0 = (band * kBand + within % rows_in_band) * G::BM, col0 = (within / rows_in_band) * G::BN;
+
+  // DMA: A stage = 24 pieces of 16 rows x 64 B (3 per wavefront), B stage = 16 pieces of 2 k-rows x 512 B (2 per wavefront)
+  unsigned voff_a[3], voff_b[2];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const unsigned row = (wave + 8 * i) * 16 + lane / 4, pc = lane % 4;
+    voff_a[i] = (min(row0 + row, N - 1) - row0) * K * 2 + (pc ^ ((0u - (row >> 2)) & 3u)) * 16;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const unsigned kr = (wave + 8 * i) * 2 + lane / 32, pb = lane % 32;
+    const unsigned lc = pb ^ ((kr & 3u) << 2) ^ (((kr >> 3) & 1u) << 1);
+    voff_b[i] = kr * M * 2 + (min(col0 + lc * 8, M - 8) - col0) * 2;
+  }
+  const char *a_base = (const char *)A + (size_t)row0 * K * 2;
+  const char *b_base = (const char *)B + (size_t)col0 * 2;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
+  const unsigned U = K / G::BK;
+  auto issue = [&](unsigned slab, unsigned buf) {
+    const unsigned sl = min(slab, U - 1);               // past the end: harmless re-fetch into a dead buffer
+    const char *ap = a_base + (size_t)sl * (G::BK * 2);
+    const char *bp = b_base + (size_t)sl * G::BK * M * 2;
+    const unsigned la0 = lds0 + buf * G::STAGE_BYTES + wave * 1024, la1 = la0 + 8 * 1024, la2 = la0 + 16 * 1024;
+    const unsigned lb0 = la0 + G::A_BYTES, lb1 = lb0 + 8 * 1024;
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\t" MM_DMA_PIECE("%1", "%6", "%8") MM_DMA_PIECE("%2", "%6", "%9") MM_DMA_PIECE("%3", "%6", "%10")
+                     MM_DMA_PIECE("%4", "%7", "%11") MM_DMA_PIECE("%5", "%7", "%12") "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff_a[0]), "v"(voff_a[1]), "v"(voff_a[2]), "v"(voff_b[0]), "v"(voff_b[1]), "s"(ap), "s"(bp), "s"(la0),
+                   "s"(la1), "s"(la2), "s"(lb0), "s"(lb1)
+                 : "memory");
+  };
+
+  // A: row = wm*96 + rb*16 + l15, chunk g, physical = g ^ (-(row>>2))&3 = g ^ (-(l15>>2))&3
+  const unsigned a_off = (wm * 96 + l15) * 64 + (g ^ ((0u - (l15 >> 2)) & 3u)) * 16;
+  // B: k = 8*g + 4*h2 + r (r = l15>>2), piece = l15&3; logical chunk = wn*16 + nb*2 + (piece>>1); physical = logical ^ X,
+  // X = (r<<2) ^ ((g&1)<<1) touches chunk bits 1..3, which is where nb sits: the address of block nb is
+  // base + (((2*nb) ^ X) << 4), one v_xad_u32 per block instead of eight address registers
+  const unsigned r = l15 >> 2, piece = l15 & 3u;
+  const unsigned b_x = ((r << 2) ^ ((g & 1u) << 1)) << 4;
+  const unsigned b_lane = G::A_BYTES + (8 * g + r) * G::BROW + (wn * 16 + (piece >> 1)) * 16 + (piece & 1u) * 8;
+
+  using f32x4 = __attribute__((ext_vector_type(4))) float;
+  f32x4 acc[RB][NB];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) acc[rb][nb] = (f32x4)0.0f;
+
+  auto sync = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // One slab: load segment (all 6 A operands, the first 4 of the 8 B operands, the DMA of slab u + 2) | barrier |
+  // compute segment (48 MFMAs; B operands 4..7 are read into the registers of 0..3 as those retire: 192 accumulator
+  // + 24 + 16 operand registers fit the 256 of a wavefront, 24 + 32 do not) | barrier.  Because the partner group
+  // still reads slab u - 1 from LDS during ITS compute segment, a refill may only target the buffer of slab u - 2:
+  // two slabs in flight instead of three (in cycles the same lead as the 256 x 256 kernel: 2 x 1536 vs 3 x 1024).
+  // LDS addresses are formed per phase from (lane part) + (stage offset held opaque in an SGPR): as loop invariants
+  // hipcc would keep one address register per (buffer, operand) alive across the loop and spill accumulators for them.
+  typedef s4 __attribute__((address_space(3))) * lds_s4_t;
+  typedef const h8 __attribute__((address_space(3))) * lds_h8_t;
+  auto read_b = [&](unsigned tb, int nb) {
+    const unsigned p = tb + (b_x ^ (unsigned)(nb * 32));
+    const s4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_t)(size_t)p);
+    const s4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_t)(size_t)(p + 4 * G::BROW));
+    return join(v0, v1);
+  };
+  const bool shifted = !(VAR & 2) && group == 1;
+  const bool early = !shifted;   // (lock-step ablation: everybody follows the early group's rules)
+  auto phase = [&](auto bufc, unsigned u) {
+    constexpr int BUF = decltype(bufc)::value;
+    unsigned so = lds0 + BUF * G::STAGE_BYTES;
+    asm volatile("" : "+s"(so));
+    const unsigned tb = b_lane + so, ta = a_off + so;
+    h8 af[RB], bf[4];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) bf[nb] = read_b(tb, nb);
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) af[rb] = *(lds_h8_t)(size_t)(ta + rb * 16 * 64);
+    // Refill protocol, asymmetric between the two groups (see the buffer-lifetime note above): the EARLY group (0) may
+    // only target the buffer of slab u - 2 (its partner still reads u - 1), issues slab u + 2 and retires its share of
+    // slab u + 1 at the END of its compute segment; the LATE group (1), one interval behind, finds the buffer of slab
+    // u - 1 free, issues slab u + 3 and retires its share of slab u + 1 at the end of its load segment -- the same barrier
+    // instance.  Every piece so has 3 (early) or 4 (late) barrier intervals to land before the first read of its slab.
+    if (early) {
+      issue(u + 2, (BUF + 2) & 3);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    } else {
+      issue(u + 3, (BUF + 3) & 3);
+      asm volatile("s_waitcnt vmcnt(10)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    sync();
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb)
+        acc[rb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[rb], bf[nb], acc[rb][nb], 0, 0, 0);
+      bf[nb] = read_b(tb, nb + 4);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb)
+        acc[rb][nb + 4] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[rb], bf[nb], acc[rb][nb + 4], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    if (early) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    sync();
+  };
+
+  issue(0, 0);
+  issue(1, 1);
+  if (!early) issue(2, 2);
+  if (early) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+  sync();
+  if (shifted) sync();
+  for (unsigned u = 0; u < U; u += 4) {
+    phase(std::integral_constant<int, 0>{}, u);
+    if (u + 1 < U) phase(std::integral_constant<int, 1>{}, u + 1);
+    if (u + 2 < U) phase(std::integral_constant<int, 2>{}, u + 2);
+    if (u + 3 < U) phase(std::integral_constant<int, 3>{}, u + 3);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (!shifted && !(VAR & 2)) sync();
+  sync();
+
+  // epilogue in two column halves of 64 (a wavefront's 96 x 128 part would need 24 KiB of staging, 8 x 24 > 160 KiB)
+  {
+    char *slice = smem + wave * (96 * 128);
+    using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+#pragma unroll
+    for (int hcol = 0; hcol < 2; ++hcol) {
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            *(_Float16 *)(slice + (rb * 16 + 4 * g + i) * 128 + (nb * 16 + l15) * 2) = (_Float16)acc[rb][hcol * 4 + nb][i];
+#pragma unroll
+      for (int it = 0; it < 96 * 8 / 64; ++it) {
+        const unsigned c = it * 64 + lane, row = c / 8, ch = c % 8;
+        const u32x4 v = *(const u32x4 *)(slice + row * 128 + ch * 16);
+        const unsigned grow = row0 + wm * 96 + row, gcol = col0 + wn * 128 + hcol * 64 + ch * 8;
+        if (grow < N && gcol < M) *(u32x4 *)(C + (size_t)grow * M + gcol) = v;
+      }
+    }
+  }
+}
+#undef MM_DMA_PIECE
 
 }  // namespace
 
@@ -866,64 +1094,136 @@ bool mfma_f16_serves(const Problem &p) {
   return !p.a_transposed || (p.n >= 8 && p.n % 8 == 0);
 }
 
+template <typename G, bool AT = false>
+static int launch_h(hipStream_t s, const Problem &p) {
+  const unsigned tiles_n = (p.n + G::BM - 1) / G::BM, tiles_m = (p.m + G::BN - 1) / G::BN;
+  static unsigned long long configured = 0;
+  if (int e = ensure_dynamic_lds((const void *)mfma_f16_kernel<G, AT>, G::LDS_BYTES, configured)) return e;
+  hipLaunchKernelGGL((mfma_f16_kernel<G, AT>), dim3(tiles_n * tiles_m), dim3(G::THREADS), G::LDS_BYTES, s,
+                     (const _Float16 *)p.a, (const _Float16 *)p.b, (_Float16 *)p.c, p.n, p.k, p.m, tiles_n, tiles_m, band_rows());
+  return (int)hipGetLastError();
+}
+
 // The DMA addresses a tile's rows with 32-bit byte offsets from a uniform 64-bit base: 256 rows x K x 2 B, and 64 k-rows
-// x M (or N, K x N layout) x 2 B, must stay below 4 GiB; longer rows are served by the slab64 kernel (64-bit addresses).
+// x M (or N, K x N layout) x 2 B, must stay below 4 GiB; longer rows are served by the round-1 kernel.
 static bool pp_reach(const Problem &p) {
   return 256ull * (p.a_transposed ? 1ull : p.k) * 2ull < (1ull << 32) && 64ull * (p.m > p.n ? p.m : p.n) * 2ull < (1ull << 32);
 }
-static bool ppk32_serves(const Problem &p) {
-  const bool shape = p.k % 32 == 0 && p.k >= 128 && p.m % 8 == 0 && p.m >= 8 && pp_reach(p);
-  return p.a_transposed ? shape && p.n % 8 == 0 && p.n >= 8 : shape && p.n >= 1;
+bool mfma_f16_pp_serves(const Problem &p) {
+  return !p.a_transposed && p.k % 32 == 0 && p.k >= 128 && p.m % 8 == 0 && p.m >= 8 && p.n >= 1 && pp_reach(p);
 }
-static bool pp64_serves(const Problem &p) { return !p.a_transposed && ppk32_serves(p) && p.k % 64 == 0 && p.k >= 256; }
+bool mfma_f16_pp_at_serves(const Problem &p) {
+  return p.a_transposed && p.k % 32 == 0 && p.k >= 128 && p.m % 8 == 0 && p.m >= 8 && p.n % 8 == 0 && p.n >= 8 && pp_reach(p);
+}
+
+template <int VAR, bool AT = false>
+static int launch_pp(hipStream_t s, const Problem &p) {
+  using G = GeoPP;
+  const unsigned tiles_n = (p.n + G::BM - 1) / G::BM, tiles_m = (p.m + G::BN - 1) / G::BN;
+  static unsigned long long configured = 0;
+  if (int e = ensure_dynamic_lds((const void *)mfma_f16_pp_kernel<VAR, AT>, G::LDS_BYTES, configured)) return e;
+  hipLaunchKernelGGL((mfma_f16_pp_kernel<VAR, AT>), dim3(tiles_n * tiles_m), dim3(G::THREADS), G::LDS_BYTES, s,
+                     (const _Float16 *)p.a, (const _Float16 *)p.b, (_Float16 *)p.c, p.n, p.k, p.m, tiles_n, tiles_m, band_rows());
+  return (int)hipGetLastError();
+}
+
+bool mfma_f16_pp2_serves(const Problem &p) { return mfma_f16_pp_serves(p) && p.k % 64 == 0 && p.k >= 256; }
+
+template <int VAR>
+static int launch_pp2(hipStream_t s, const Problem &p) {
+  using G = GeoPP2;
+  const unsigned tiles_n = (p.n + G::BM - 1) / G::BM, tiles_m = (p.m + G::BN - 1) / G::BN;
+  static unsigned long long configured = 0;
+  if (int e = ensure_dynamic_lds((const void *)mfma_f16_pp2_kernel<VAR>, G::LDS_BYTES, configured)) return e;
+  hipLaunchKernelGGL((mfma_f16_pp2_kernel<VAR>), dim3(tiles_n * tiles_m), dim3(G::THREADS), G::LDS_BYTES, s,
+                     (const _Float16 *)p.a, (const _Float16 *)p.b, (_Float16 *)p.c, p.n, p.k, p.m, tiles_n, tiles_m, band_rows());
+  return (int)hipGetLastError();
+}
+
+template <int VAR>
+static int launch_pp2s(hipStream_t s, const Problem &p) {
+  using G = GeoPP2;
+  const unsigned tiles_n = (p.n + G::BM - 1) / G::BM, tiles_m = (p.m + G::BN - 1) / G::BN;
+  static unsigned long long configured = 0;
+  if (int e = ensure_dynamic_lds((const void *)mfma_f16_pp2s_kernel<VAR>, G::LDS_BYTES, configured)) return e;
+  hipLaunchKernelGGL((mfma_f16_pp2s_kernel<VAR>), dim3(tiles_n * tiles_m), dim3(G::THREADS), G::LDS_BYTES, s,
+                     (const _Float16 *)p.a, (const _Float16 *)p.b, (_Float16 *)p.c, p.n, p.k, p.m, tiles_n, tiles_m, band_rows());
+  return (int)hipGetLastError();
+}
+
+template <int VAR>
+static int launch_pp3(hipStream_t s, const Problem &p) {
+  using G = GeoPP3;
+  const unsigned tiles_n = (p.n + G::BM - 1) / G::BM, tiles_m = (p.m + G::BN - 1) / G::BN;
+  static unsigned long long configured = 0;
+  if (int e = ensure_dynamic_lds((const void *)mfma_f16_pp3_kernel<VAR>, G::LDS_BYTES, configured)) return e;
+  hipLaunchKernelGGL((mfma_f16_pp3_kernel<VAR>), dim3(tiles_n * tiles_m), dim3(G::THREADS), G::LDS_BYTES, s,
+                     (const _Float16 *)p.a, (const _Float16 *)p.b, (_Float16 *)p.c, p.n, p.k, p.m, tiles_n, tiles_m, band_rows());
+  return (int)hipGetLastError();
+}
 
 int mfma_f16_tile(const Problem &p) {  // 0: 256x256, 4: 128x256
   static const TileCandidate cands[] = {{0, 256, 256, 1, 1.00}, {4, 128, 256, 1, 0.80}};
   return p.a_transposed ? 0 : pick_tile(cands, 2, p.n, p.m);
 }
 
-// The one place that decides which kernel a (problem, f16_variant knob) pair runs; mm_kernel_name and the launcher
-// both go through it.  f16_variant: -1 the best the shape allows; 0 slab64; 4 slab64 on the 128 x 256 tile;
-// 11 pingpong_k32; 100 pingpong_32x32x16; 200 pingpong_16x16x32.  A pinned kernel that cannot serve the shape falls
-// through to the next one down (as the default does), so a knob never turns a servable problem into an error.
-static Kind resolve(const Problem &p) {
-  if (!mfma_f16_serves(p)) return K_NONE;
-  const int v = tuning(TUNE_F16_VARIANT);
-  if (!(v < 0 || v == 0 || v == 4 || v == 11 || v == 100 || v == 200)) return K_NONE;   // lab ids are not in this library
-  if (p.a_transposed) return (v != 0 && ppk32_serves(p)) ? K_PPK32_AT : K_SLAB64_AT;
-  if (v == 4 || (v < 0 && mfma_f16_tile(p) == 4)) return K_SLAB64_128;
-  if (v == 0) return K_SLAB64;
-  if ((v < 0 || v == 200) && pp64_serves(p)) return K_PP16;   // +7 % over pingpong_32x32x16 (profiles/r03c_*)
-  if (v == 100 && pp64_serves(p)) return K_PP32;              // round 2's default: +2-4 % over pingpong_k32 (profiles/r02h_*)
-  if (ppk32_serves(p)) return K_PPK32;
-  return K_SLAB64;
-}
-
-const char *mfma_f16_name(const Problem &p) { return kNames[resolve(p)]; }
-
-template <typename Kern>
-static int launch_tile(hipStream_t s, const Problem &p, Kern kern, unsigned bm, unsigned bn, unsigned threads, int lds,
-                       unsigned long long &configured) {
-  const unsigned tiles_n = (p.n + bm - 1) / bm, tiles_m = (p.m + bn - 1) / bn;
-  if (int e = ensure_dynamic_lds((const void *)kern, lds, configured)) return e;
-  hipLaunchKernelGGL(kern, dim3(tiles_n * tiles_m), dim3(threads), lds, s, (const _Float16 *)p.a, (const _Float16 *)p.b,
-                     (_Float16 *)p.c, p.n, p.k, p.m, tiles_n, tiles_m, band_rows(bm, bn, 1));
-  return (int)hipGetLastError();
-}
+const char *mfma_f16_name(const Problem &) { return "mfma_f16_lab"; }   // the lab does not name its schedules
 
 int launch_mfma_f16(hipStream_t s, const Problem &p) {
-  static unsigned long long cfg[K_NONE] = {};
-  const Kind k = resolve(p);
-  switch (k) {
-    case K_PP16: return launch_tile(s, p, mfma_f16_pp2s_kernel, 256, 256, GeoPP2::THREADS, GeoPP2::LDS_BYTES, cfg[k]);
-    case K_PP32: return launch_tile(s, p, mfma_f16_pp2_kernel, 256, 256, GeoPP2::THREADS, GeoPP2::LDS_BYTES, cfg[k]);
-    case K_PPK32: return launch_tile(s, p, mfma_f16_pp_kernel<false>, 256, 256, GeoPP::THREADS, GeoPP::LDS_BYTES, cfg[k]);
-    case K_PPK32_AT: return launch_tile(s, p, mfma_f16_pp_kernel<true>, 256, 256, GeoPP::THREADS, GeoPP::LDS_BYTES, cfg[k]);
-    case K_SLAB64: return launch_tile(s, p, mfma_f16_kernel<GeoH, false>, GeoH::BM, GeoH::BN, GeoH::THREADS, GeoH::LDS_BYTES, cfg[k]);
-    case K_SLAB64_AT: return launch_tile(s, p, mfma_f16_kernel<GeoH, true>, GeoH::BM, GeoH::BN, GeoH::THREADS, GeoH::LDS_BYTES, cfg[k]);
-    case K_SLAB64_128: return launch_tile(s, p, mfma_f16_kernel<GeoHS, false>, GeoHS::BM, GeoHS::BN, GeoHS::THREADS, GeoHS::LDS_BYTES, cfg[k]);
-    default: return kErrNotSupported;
+  if (!mfma_f16_serves(p)) return kErrNotSupported;
+  const int v = tuning(TUNE_F16_VARIANT);  // tuning hook
+  if (p.a_transposed) {  // K x N A: ping-pong when the shape allows it (variant 0 pins the round-1 kernel)
+    if (v != 0 && mfma_f16_pp_at_serves(p)) return launch_pp<1, true>(s, p);
+    return launch_h<GeoH, true>(s, p);
   }
+  if (v == 300 && mfma_f16_pp_serves(p)) return launch_pp3<0>(s, p);    // 384 x 256 tile, 16x16x32
+  if (v == 302 && mfma_f16_pp_serves(p)) return launch_pp3<2>(s, p);
+  if (v == 200 && mfma_f16_pp2_serves(p)) return launch_pp2s<0>(s, p);   // 16x16x32 matrix instruction
+  if (v == 202 && mfma_f16_pp2_serves(p)) return launch_pp2s<2>(s, p);   // its lock-step ablation
+  if (v >= 100 && v < 200 && mfma_f16_pp2_serves(p)) {  // 100 + VAR of the full-line-A ping-pong kernel
+    switch (v - 100) {
+      case 0: return launch_pp2<0>(s, p);
+      case 2: return launch_pp2<2>(s, p);     // lock step (ablation)
+      case 4: return launch_pp2<4>(s, p);     // A nt
+      case 8: return launch_pp2<8>(s, p);     // A sc1
+      case 16: return launch_pp2<16>(s, p);   // B nt
+      case 32: return launch_pp2<32>(s, p);   // B sc1
+      case 20: return launch_pp2<20>(s, p);   // A nt, B nt
+      case 40: return launch_pp2<40>(s, p);   // A sc1, B sc1
+      case 60: return launch_pp2<60>(s, p);   // A sc0 sc1, B sc0 sc1
+      default: return kErrNotSupported;
+    }
+  }
+  if (v >= 10 && v < 100 && mfma_f16_pp_serves(p)) {  // 10 + VAR of the ping-pong kernel
+    // VAR bits 4-6 skip work on purpose (wrong results): only for the power-breakdown measurements
+    if (((v - 10) & 0x70) && tuning(TUNE_ABLATIONS) != 1) return kErrNotSupported;
+    switch (v - 10) {
+      case 0: return launch_pp<0>(s, p);
+      case 1: return launch_pp<1>(s, p);
+      case 2: return launch_pp<2>(s, p);
+      case 3: return launch_pp<3>(s, p);
+      case 4: return launch_pp<4>(s, p);
+      case 5: return launch_pp<5>(s, p);
+      case 9: return launch_pp<9>(s, p);
+      case 13: return launch_pp<13>(s, p);
+      case 17: return launch_pp<17>(s, p);  // ablation: no DMA
+      case 33: return launch_pp<33>(s, p);  // ablation: no fragment reads
+      case 49: return launch_pp<49>(s, p);  // ablation: neither
+      case 65: return launch_pp<65>(s, p);  // ablation: every workgroup streams the same panels (L2-resident)
+      default: return kErrNotSupported;
+    }
+  }
+  if (v == 1) return launch_h<GeoH4>(s, p);
+  if (v == 2) return launch_h<GeoH32x4>(s, p);
+  if (v == 3) return launch_h<GeoH32x3>(s, p);
+  if (v == 4) return launch_h<GeoHS>(s, p);
+  if (v == 0) return launch_h<GeoH>(s, p);
+  // default: the shape-adaptive tile pick; where that is the 256 x 256 tile and the shape allows it,
+  // the ping-pong schedule (84-89 % MFMA utilisation vs 67 %, profiles/r02d_pmc_f16_32768_v*.json)
+  if (mfma_f16_tile(p) == 4) return launch_h<GeoHS>(s, p);
+  if (mfma_f16_pp2_serves(p)) return launch_pp2s<0>(s, p);  // 16x16x32 instruction: +7 % over pp2 (profiles/r03c_*); pp2: +2-4 % over pp (r02h_*)
+  if (mfma_f16_pp_serves(p)) return launch_pp<1>(s, p);
+  return launch_h<GeoH>(s, p);
 }
 
 }  // namespace mm

@@ -1,3 +1,6 @@
+// LAB EDITION (tools/lab, built into libmm_gemm_amd_lab.so only): includes the no-DMA / L2-resident ablations (split_variant
+// 16 / 32, WRONG results on purpose, MM_ABLATIONS=1).  The product file is gemm_hls_amd/csrc/mm_mfma_f32_split.hip.
+//
 // fp32 (Multiply, Add) on the bf16 matrix cores: C = A x B with every fp32 operand split into three
 // bf16 planes, x = x1 + x2 + x3 (x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2); each
 // subtraction is exact in fp32, so the three planes carry all 24 significand bits), and the six
@@ -31,10 +34,9 @@
 // The workspace (6 bytes per element of A and B, padded to whole blocks/slabs) is allocated
 // stream-ordered (hipMallocAsync / hipFreeAsync on the launch stream): no hidden global state, safe
 // for concurrent launches, and the pool keeps the memory between launches.
-#include <mutex>
 #include <type_traits>
 
-#include "mm_common.h"
+#include "../../gemm_hls_amd/csrc/mm_common.h"
 
 namespace mm {
 namespace {
@@ -129,7 +131,8 @@ __device__ __forceinline__ const char *uniform(const char *p) {
 
 // ---- step 2: GEMM over the packed planes -----------------------------------------------------------
 // VAR bit 0: s_setprio(1) around the MFMA groups; bit 1: no chunked flush (one chain over all of K).
-// (The no-DMA / L2-resident-source ablations of the power breakdown live in tools/lab/lab_mfma_f32_split.hip.)
+// Ablations (WRONG results by construction; refused unless the "ablations" knob is set): bit 2: no DMA in the main
+// loop; bit 3: every workgroup streams block 0's slabs (all DMA traffic becomes L2 hits).
 // bit 4: fragment reads interleaved one by one with the MFMAs (sched_group_barrier) instead of issued in front of them;
 // bit 5: flush every 4128 k instead of every 8256; bit 6: ping-pong schedule (see pp_stage).
 // TERMS: 6 (default) or 3 (a1b2 + a2b1 + a1b1 only:
@@ -158,8 +161,10 @@ void mfma_f32_split_kernel(const char *__restrict__ Ap, const char *__restrict__
   // ---- DMA: wavefront w moves fragment w of each plane of the tile's A slab and B slab (1 KiB pieces: source plane
   // stride 8 KiB in the packed layout, LDS plane stride FR KiB); a 128-row tile is one half of a packed 256-row block
   const unsigned voff0 = wave * 1024 + lane * 16, voff1 = voff0 + 8 * 1024, voff2 = voff0 + 16 * 1024;
-  const char *a_base = Ap + (size_t)(tile_r / G::HALVES) * slabs * Packed::SLAB_BYTES + (tile_r % G::HALVES) * G::FR * Packed::FRAG_BYTES;
-  const char *b_base = Bp + (size_t)(tile_c / G::HALVES) * slabs * Packed::SLAB_BYTES + (tile_c % G::HALVES) * G::FR * Packed::FRAG_BYTES;
+  const char *a_base = Ap + ((VAR & 8) ? 0 : (size_t)(tile_r / G::HALVES) * slabs * Packed::SLAB_BYTES +
+                                                 (tile_r % G::HALVES) * G::FR * Packed::FRAG_BYTES);
+  const char *b_base = Bp + ((VAR & 8) ? 0 : (size_t)(tile_c / G::HALVES) * slabs * Packed::SLAB_BYTES +
+                                                 (tile_c % G::HALVES) * G::FR * Packed::FRAG_BYTES);
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
   auto issue = [&](unsigned slab, unsigned buf) {
     const unsigned sl = min(slab, slabs - 1);  // past the end: harmless re-fetch into a dead buffer
@@ -254,7 +259,7 @@ void mfma_f32_split_kernel(const char *__restrict__ Ap, const char *__restrict__
     if constexpr (PIECES == 6) asm volatile("s_waitcnt vmcnt(6)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(4)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
     sync();                                 // stage s+1 is published, buffer BUF is free
-    issue(s + 3, BUF);
+    if (!(VAR & 4)) issue(s + 3, BUF);
     read_b(nxt, bf[PAR ^ 1]);
     read_a(nxt, 0, af[0]);
     mac(TM - 1, af[(TM - 1) & 1], bf[PAR]);
@@ -283,7 +288,7 @@ void mfma_f32_split_kernel(const char *__restrict__ Ap, const char *__restrict__
     read_b(cur, bf[0]);
 #pragma unroll
     for (int mi = 0; mi < TM; ++mi) read_a(cur, mi, paf[mi]);
-    issue(s + 2, (BUF + 2) % 3);
+    if (!(VAR & 4)) issue(s + 2, (BUF + 2) % 3);
     if constexpr (PIECES == 6) asm volatile("s_waitcnt vmcnt(6)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(4)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
     sync();
@@ -473,72 +478,55 @@ size_t mfma_f32_split_workspace_bytes(const Problem &p) {
   return ((size_t)((p.n + 255) / 256) + (size_t)((p.m + 255) / 256)) * slabs * Packed::SLAB_BYTES;
 }
 
-
-// One library-owned memory pool per device for the packed planes.
-static hipMemPool_t g_split_pool[64] = {};
-static int split_pool(int dev, hipMemPool_t *out) {
-  static std::mutex mu;
-  std::lock_guard<std::mutex> lock(mu);
-  hipMemPool_t &pool = g_split_pool[dev & 63];
-  if (!pool) {
-    hipMemPoolProps props = {};
-    props.allocType = hipMemAllocationTypePinned;
-    props.handleTypes = hipMemHandleTypeNone;
-    props.location.type = hipMemLocationTypeDevice;
-    props.location.id = dev;
-    hipError_t e = hipMemPoolCreate(&pool, &props);
-    if (e != hipSuccess) { pool = nullptr; return (int)e; }
-    unsigned long long keep = ~0ull;
-    if ((e = hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep)) != hipSuccess) return (int)e;
-  }
-  *out = pool;
-  return 0;
-}
-// mm_release_workspace(): hand the cached workspace of `dev` back to the driver (the caller has synchronised)
-int mfma_f32_split_release(int dev) {
-  hipMemPool_t pool = g_split_pool[dev & 63];
-  return pool ? (int)hipMemPoolTrimTo(pool, 0) : 0;
+int mfma_f32_split_release(int dev) {   // the lab edition still caches its workspace in the device's default pool
+  hipMemPool_t pool;
+  hipError_t e = hipDeviceGetDefaultMemPool(&pool, dev);
+  return e != hipSuccess ? (int)e : (int)hipMemPoolTrimTo(pool, 0);
 }
 
 // variant (split_variant knob): -1 / 0 = default (6 products, ping-pong schedule, flush every 8256 k); otherwise a bit
 // mask: 1 first schedule of the round (one barrier per stage, fragment reads ahead of each MFMA group, s_setprio around
 // the group), 2 three products (planes 1 and 2 only), 4 no flush, 8 plain hipMalloc/hipFree workspace (diagnosis),
+// 16 no DMA in the main loop, 32 L2-resident sources (these two: ablations on the one-barrier schedule, see the kernel),
 // 64 flush every 4128 k, 128 one barrier per stage with the fragment reads interleaved between the MFMAs,
 // 256 / 512 pin the 256 x 256 / 128 x 128 tile (default: by shape, mfma_f32_split_tile)
 int launch_mfma_f32_split(hipStream_t s, const Problem &p, int variant) {
   const unsigned slabs = (p.k + 15) / 16;
   const unsigned blocks_a = (p.n + 255) / 256, blocks_b = (p.m + 255) / 256;
   const size_t a_bytes = (size_t)blocks_a * slabs * Packed::SLAB_BYTES, b_bytes = (size_t)blocks_b * slabs * Packed::SLAB_BYTES;
-  // The workspace comes from a pool this library owns (one per device, created on first use, release threshold
-  // "never"): freed workspace stays cached between launches without touching the process's default pool, whose
-  // settings belong to the application.  mm_release_workspace() trims it.
+  // keep freed workspace in the device's pool between launches (the default threshold of 0 hands it back
+  // to the driver at the next synchronisation, and the next launch pays a multi-GiB allocation again)
+  static unsigned long long pool_configured = 0;
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return (int)e;
-  hipMemPool_t pool = nullptr;
-  if (int rc = split_pool(dev, &pool)) return rc;
+  if (!(__atomic_load_n(&pool_configured, __ATOMIC_ACQUIRE) & (1ull << (dev & 63)))) {
+    hipMemPool_t pool;
+    unsigned long long keep = ~0ull;
+    if ((e = hipDeviceGetDefaultMemPool(&pool, dev)) != hipSuccess) return (int)e;
+    if ((e = hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep)) != hipSuccess) return (int)e;
+    __atomic_fetch_or(&pool_configured, 1ull << (dev & 63), __ATOMIC_RELEASE);
+  }
   char *ws = nullptr;
   const int v = variant < 0 ? 0 : variant;
-  if (v & 48) return kErrNotSupported;   // (ablation ids of the lab build)
+  if ((v & 48) && tuning(TUNE_ABLATIONS) != 1) return kErrNotSupported;
   const bool sync_alloc = v & 8;
   if (sync_alloc) e = hipMalloc((void **)&ws, a_bytes + b_bytes);
-  else e = hipMallocFromPoolAsync((void **)&ws, a_bytes + b_bytes, pool, s);
+  else e = hipMallocAsync((void **)&ws, a_bytes + b_bytes, s);
   if (e != hipSuccess) return (int)e;
   const float *a = (const float *)p.a, *b = (const float *)p.b;
-  (void)hipGetLastError();   // a stale error of the application's own calls must not be reported as this launch's
   if (p.a_transposed)
     hipLaunchKernelGGL((split_pack_kernel<false, false>), dim3(slabs, blocks_a), dim3(512), 0, s, a, ws, p.n, p.k, p.n, slabs);
   else
     hipLaunchKernelGGL((split_pack_kernel<true, false>), dim3(slabs, blocks_a), dim3(512), 0, s, a, ws, p.n, p.k, p.k, slabs);
+  hipLaunchKernelGGL((split_pack_kernel<false, true>), dim3(slabs, blocks_b), dim3(512), 0, s, b, ws + a_bytes, p.m, p.k, p.m,
+                     slabs);
   int rc = (int)hipGetLastError();
   if (rc == 0) {
-    hipLaunchKernelGGL((split_pack_kernel<false, true>), dim3(slabs, blocks_b), dim3(512), 0, s, b, ws + a_bytes, p.m, p.k, p.m,
-                       slabs);
-    rc = (int)hipGetLastError();
-  }
-  if (rc == 0) {
     const char *bp = ws + a_bytes;
-    if (v & 1) rc = launch_gemm<1, 6>(s, ws, bp, p, slabs);
+    if (v & 16) rc = launch_gemm<16 | 2 | 4, 6>(s, ws, bp, p, slabs);
+    else if (v & 32) rc = launch_gemm<16 | 2 | 8, 6>(s, ws, bp, p, slabs);
+    else if (v & 1) rc = launch_gemm<1, 6>(s, ws, bp, p, slabs);
     else if ((v & 128) && (v & 4)) rc = launch_gemm<16 | 2, 6>(s, ws, bp, p, slabs);
     else if (v & 128) rc = launch_gemm<16, 6>(s, ws, bp, p, slabs);
     else if (v & 2) rc = launch_gemm<64, 3>(s, ws, bp, p, slabs);

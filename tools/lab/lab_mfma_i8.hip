@@ -1,5 +1,8 @@
-// int8_t / uint8_t (Multiply, Add) fast path for gfx950 on the int8 matrix-core instructions
-// (v_mfma_i32_16x16x64_i8 / v_mfma_i32_32x32x32_i8).
+// LAB EDITION (tools/lab, built into libmm_gemm_amd_lab.so only): the schedules, cache-policy experiments, tile shapes
+// and ablations (some return WRONG results on purpose; they need MM_ABLATIONS=1) behind the numbers under profiles/.
+// The product file is gemm_hls_amd/csrc/mm_mfma_i8.hip.
+//
+// int8_t / uint8_t (Multiply, Add) fast path for gfx950 on v_mfma_i32_32x32x32_i8.
 //
 // Why the signed-int8 matrix core serves BOTH element types exactly: the reference's semiring on
 // an 8-bit Data_t wraps every product and every sum to 8 bits (hlslib::op::Multiply/Add return
@@ -9,10 +12,7 @@
 // (include/Utility.h:18-42) for int8_t and for uint8_t (the type the reference special-cases at
 // CMakeLists.txt:46-47).  Checked against the oracle in tests/test_gpu_parity.py.
 //
-// Kernels in this file, as in mm_mfma_f16.hip: pingpong_16x16x64 (default: K % 128 == 0, K >= 512, row-major A),
-// pingpong_32x32x32 (cross-check, i8_variant 100), pingpong_k64 (K % 64 == 0; row-major and K x N A), slab128 (K % 32 == 0).
-// Lock-step ablations: tools/lab/lab_mfma_i8.hip.
-// Organisation of slab128 as mm_mfma_f16.hip's slab64: 256 x 256 x 128(bytes) slabs, 8 wavefronts of 64 x 128, A operand
+// Organisation as mm_mfma_f16.hip: 256 x 256 x 128(bytes) slabs, 8 wavefronts of 64 x 128, A operand
 // by one ds_read_b128 (16 consecutive k of a row, rows swizzled with (row>>1)&7), B operand (16
 // consecutive k of ONE column of the row-major B) by two ds_read_b64_tr_b8: lane i of a 16-lane
 // group receives column i of the [8 k][16 col] block whose rows the group's lanes point at,
@@ -25,7 +25,7 @@
 #include <cstdlib>
 #include <type_traits>
 
-#include "mm_common.h"
+#include "../../gemm_hls_amd/csrc/mm_common.h"
 
 namespace mm {
 namespace {
@@ -265,7 +265,7 @@ struct GeoI8PP {
 };
 #define MM_DMA_PIECE(vo, sb, la) "s_mov_b32 m0, " la "\n\ts_nop 0\n\tglobal_load_lds_dwordx4 " vo ", " sb "\n\t"
 
-template <bool AT>  // AT: A stored K x N, staged and gathered like B
+template <int VAR, bool AT = false>  // VAR bit 1: lock-step ablation; AT: A stored K x N, staged and gathered like B
 __global__ __launch_bounds__(GeoI8PP::THREADS) void mfma_i8_pp_kernel(const signed char *__restrict__ A,
                                                                         const signed char *__restrict__ B,
                                                                         signed char *__restrict__ C, unsigned N, unsigned K,
@@ -387,7 +387,7 @@ __global__ __launch_bounds__(GeoI8PP::THREADS) void mfma_i8_pp_kernel(const sign
   issue(2, 2);
   asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   sync();
-  const bool shifted = group == 1;
+  const bool shifted = !(VAR & 2) && group == 1;
   if (shifted) sync();
   for (unsigned u = 0; u < U; u += 4) {
     phase(std::integral_constant<int, 0>{}, u);
@@ -396,7 +396,7 @@ __global__ __launch_bounds__(GeoI8PP::THREADS) void mfma_i8_pp_kernel(const sign
     if (u + 3 < U) phase(std::integral_constant<int, 3>{}, u + 3);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (!shifted) sync();
+  if (!shifted && !(VAR & 2)) sync();
   sync();
 
   // epilogue: low 8 bits of the i32 sums through this wave's 8 KiB slice, 16-B global stores
@@ -433,6 +433,7 @@ struct GeoI8PP2 {
   static constexpr int BROW = BN;
 };
 
+template <int VAR>
 __global__ __launch_bounds__(GeoI8PP2::THREADS) void mfma_i8_pp2_kernel(const signed char *__restrict__ A,
                                                                          const signed char *__restrict__ B,
                                                                          signed char *__restrict__ C, unsigned N, unsigned K,
@@ -552,7 +553,7 @@ __global__ __launch_bounds__(GeoI8PP2::THREADS) void mfma_i8_pp2_kernel(const si
   issue_b(2, 2);
   asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   sync();
-  const bool shifted = group == 1;
+  const bool shifted = !(VAR & 2) && group == 1;
   if (shifted) sync();
   unsigned ab = 0;
   for (unsigned u = 0; u < U; u += 4) {
@@ -566,7 +567,7 @@ __global__ __launch_bounds__(GeoI8PP2::THREADS) void mfma_i8_pp2_kernel(const si
     ab = ab1 == 2 ? 0 : ab1 + 1;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (!shifted) sync();
+  if (!shifted && !(VAR & 2)) sync();
   sync();
 
   {
@@ -591,8 +592,8 @@ __global__ __launch_bounds__(GeoI8PP2::THREADS) void mfma_i8_pp2_kernel(const si
   }
 }
 
-// pingpong_16x16x64 (round 3, the default): same tile, rings, DMA and segment protocol as
-// pingpong_32x32x32, the matrix instruction in its 16 x 16 x 64 form (4 accumulator registers, 16 cycles) -- on full-range random
+// Ping-pong kernel on v_mfma_i32_16x16x64_i8 ("pp2s", round 3): same tile, rings, DMA and segment protocol as
+// pp2, the matrix instruction in its 16 x 16 x 64 form (4 accumulator registers, 16 cycles) -- on full-range random
 // bytes the register-only loop of this form holds 1.97 GHz = 4.09 POp/s where the 32x32x32 form holds 1.67 GHz =
 // 3.50 POp/s (profiles/r03b_probe_mfma_power_by_shape_and_operand_order.txt), and the kernel is power-limited.
 // A wavefront's 128 x 64 block is 8 x 4 accumulators; a 64-deep slab is ONE MFMA k: 8 A operands (ds_read_b128:
@@ -601,6 +602,7 @@ __global__ __launch_bounds__(GeoI8PP2::THREADS) void mfma_i8_pp2_kernel(const si
 // instead of in column by 16, so the chunk index is XORed with ((k&7)<<1) | ((k>>4)&1): the 16 k-rows a half-wave
 // touches fall into the 16 different chunks of the 256-byte bank row.  Integer sums: bit-identical to every
 // other schedule and to Naive.
+template <int VAR>
 __global__ __launch_bounds__(GeoI8PP2::THREADS) void mfma_i8_pp2s_kernel(const signed char *__restrict__ A,
                                                                           const signed char *__restrict__ B,
                                                                           signed char *__restrict__ C, unsigned N, unsigned K,
@@ -714,7 +716,7 @@ __global__ __launch_bounds__(GeoI8PP2::THREADS) void mfma_i8_pp2s_kernel(const s
   issue_b(2, 2);
   asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   sync();
-  const bool shifted = group == 1;
+  const bool shifted = !(VAR & 2) && group == 1;
   if (shifted) sync();
   unsigned ab = 0;
   for (unsigned u = 0; u < U; u += 4) {
@@ -728,7 +730,7 @@ __global__ __launch_bounds__(GeoI8PP2::THREADS) void mfma_i8_pp2s_kernel(const s
     ab = ab1 == 2 ? 0 : ab1 + 1;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (!shifted) sync();
+  if (!shifted && !(VAR & 2)) sync();
   sync();
 
   {  // C/D of the 16x16 form: column l15, rows 4*g + i
@@ -751,11 +753,6 @@ __global__ __launch_bounds__(GeoI8PP2::THREADS) void mfma_i8_pp2s_kernel(const s
 }
 #undef MM_DMA_PIECE
 
-enum Kind { K_PP16, K_PP32, K_PPK64, K_PPK64_AT, K_SLAB128, K_SLAB128_AT, K_NONE };
-const char *const kNames[] = {"mfma_i8_256x256_pingpong_16x16x64", "mfma_i8_256x256_pingpong_32x32x32", "mfma_i8_256x256_pingpong_k64",
-                              "mfma_i8_256x256_pingpong_k64_KxN", "mfma_i8_256x256x128_slab128", "mfma_i8_256x256x128_slab128_KxN",
-                              "unsupported"};
-
 }  // namespace
 
 bool mfma_i8_serves(const Problem &p) {
@@ -767,49 +764,76 @@ bool mfma_i8_serves(const Problem &p) {
 static bool pp_reach(const Problem &p) {
   return 256ull * (p.a_transposed ? 1ull : p.k) < (1ull << 32) && 128ull * (p.m > p.n ? p.m : p.n) < (1ull << 32);
 }
-static bool ppk64_serves(const Problem &p) {
-  const bool shape = p.k % 64 == 0 && p.k >= 256 && p.m % 16 == 0 && p.m >= 16 && pp_reach(p);
-  return p.a_transposed ? shape && p.n % 16 == 0 && p.n >= 16 : shape && p.n >= 1;
-}
-static bool pp128_serves(const Problem &p) { return !p.a_transposed && ppk64_serves(p) && p.k % 128 == 0 && p.k >= 512; }
-
-// i8_variant: -1 the best the shape allows; 0 slab128; 10 pingpong_k64; 100 pingpong_32x32x32; 200 pingpong_16x16x64
-// (one resolver for mm_kernel_name and the launcher; a pinned kernel that cannot serve the shape falls through).
-static Kind resolve(const Problem &p) {
-  if (!mfma_i8_serves(p)) return K_NONE;
-  const int v = tuning(TUNE_I8_VARIANT);
-  if (!(v < 0 || v == 0 || v == 10 || v == 100 || v == 200)) return K_NONE;   // lab ids are not in this library
-  if (p.a_transposed) return (v != 0 && ppk64_serves(p)) ? K_PPK64_AT : K_SLAB128_AT;
-  if (v == 0) return K_SLAB128;
-  if ((v < 0 || v == 200) && pp128_serves(p)) return K_PP16;  // +7.6 % over pingpong_32x32x32 (profiles/r03e_*)
-  if (v == 100 && pp128_serves(p)) return K_PP32;
-  if (ppk64_serves(p)) return K_PPK64;
-  return K_SLAB128;
+bool mfma_i8_pp_serves(const Problem &p) {
+  return !p.a_transposed && p.k % 64 == 0 && p.k >= 256 && p.m % 16 == 0 && p.m >= 16 && p.n >= 1 && pp_reach(p);
 }
 
-const char *mfma_i8_name(const Problem &p) { return kNames[resolve(p)]; }
+bool mfma_i8_pp_at_serves(const Problem &p) {
+  return p.a_transposed && p.k % 64 == 0 && p.k >= 256 && p.m % 16 == 0 && p.m >= 16 && p.n % 16 == 0 && p.n >= 16 && pp_reach(p);
+}
 
-template <typename Kern>
-static int launch_tile(hipStream_t s, const Problem &p, Kern kern, unsigned threads, int lds, unsigned long long &configured) {
-  const unsigned tiles_n = (p.n + 255) / 256, tiles_m = (p.m + 255) / 256;
-  if (int e = ensure_dynamic_lds((const void *)kern, lds, configured)) return e;
-  hipLaunchKernelGGL(kern, dim3(tiles_n * tiles_m), dim3(threads), lds, s, (const signed char *)p.a, (const signed char *)p.b,
-                     (signed char *)p.c, p.n, p.k, p.m, tiles_n, tiles_m, band_rows());
+template <int VAR, bool AT = false>
+static int launch_i8_pp(hipStream_t s, const Problem &p) {
+  using G = GeoI8PP;
+  const unsigned tiles_n = (p.n + G::BM - 1) / G::BM, tiles_m = (p.m + G::BN - 1) / G::BN;
+  static unsigned long long configured = 0;
+  if (int e = ensure_dynamic_lds((const void *)mfma_i8_pp_kernel<VAR, AT>, G::LDS_BYTES, configured)) return e;
+  hipLaunchKernelGGL((mfma_i8_pp_kernel<VAR, AT>), dim3(tiles_n * tiles_m), dim3(G::THREADS), G::LDS_BYTES, s,
+                     (const signed char *)p.a, (const signed char *)p.b, (signed char *)p.c, p.n, p.k, p.m, tiles_n, tiles_m,
+                     band_rows());
   return (int)hipGetLastError();
 }
 
+bool mfma_i8_pp2_serves(const Problem &p) { return mfma_i8_pp_serves(p) && p.k % 128 == 0 && p.k >= 512; }
+
+static int launch_i8_pp2(hipStream_t s, const Problem &p) {
+  using G = GeoI8PP2;
+  const unsigned tiles_n = (p.n + G::BM - 1) / G::BM, tiles_m = (p.m + G::BN - 1) / G::BN;
+  static unsigned long long configured = 0;
+  if (int e = ensure_dynamic_lds((const void *)mfma_i8_pp2_kernel<0>, G::LDS_BYTES, configured)) return e;
+  hipLaunchKernelGGL((mfma_i8_pp2_kernel<0>), dim3(tiles_n * tiles_m), dim3(G::THREADS), G::LDS_BYTES, s,
+                     (const signed char *)p.a, (const signed char *)p.b, (signed char *)p.c, p.n, p.k, p.m, tiles_n, tiles_m,
+                     band_rows());
+  return (int)hipGetLastError();
+}
+
+static int launch_i8_pp2s(hipStream_t s, const Problem &p) {
+  using G = GeoI8PP2;
+  const unsigned tiles_n = (p.n + G::BM - 1) / G::BM, tiles_m = (p.m + G::BN - 1) / G::BN;
+  static unsigned long long configured = 0;
+  if (int e = ensure_dynamic_lds((const void *)mfma_i8_pp2s_kernel<0>, G::LDS_BYTES, configured)) return e;
+  hipLaunchKernelGGL((mfma_i8_pp2s_kernel<0>), dim3(tiles_n * tiles_m), dim3(G::THREADS), G::LDS_BYTES, s,
+                     (const signed char *)p.a, (const signed char *)p.b, (signed char *)p.c, p.n, p.k, p.m, tiles_n, tiles_m,
+                     band_rows());
+  return (int)hipGetLastError();
+}
+
+const char *mfma_i8_name(const Problem &) { return "mfma_i8_lab"; }   // the lab does not name its schedules
+
 int launch_mfma_i8(hipStream_t s, const Problem &p) {
-  static unsigned long long cfg[K_NONE] = {};
-  const Kind k = resolve(p);
-  switch (k) {
-    case K_PP16: return launch_tile(s, p, mfma_i8_pp2s_kernel, GeoI8PP2::THREADS, GeoI8PP2::LDS_BYTES, cfg[k]);
-    case K_PP32: return launch_tile(s, p, mfma_i8_pp2_kernel, GeoI8PP2::THREADS, GeoI8PP2::LDS_BYTES, cfg[k]);
-    case K_PPK64: return launch_tile(s, p, mfma_i8_pp_kernel<false>, GeoI8PP::THREADS, GeoI8PP::LDS_BYTES, cfg[k]);
-    case K_PPK64_AT: return launch_tile(s, p, mfma_i8_pp_kernel<true>, GeoI8PP::THREADS, GeoI8PP::LDS_BYTES, cfg[k]);
-    case K_SLAB128: return launch_tile(s, p, mfma_i8_kernel<false>, GeoI8::THREADS, GeoI8::LDS_BYTES, cfg[k]);
-    case K_SLAB128_AT: return launch_tile(s, p, mfma_i8_kernel<true>, GeoI8::THREADS, GeoI8::LDS_BYTES, cfg[k]);
-    default: return kErrNotSupported;
+  if (!mfma_i8_serves(p)) return kErrNotSupported;
+  // i8_variant knob: 0 = one-slab-per-barrier kernel, 10 = ping-pong, 12 = ping-pong in lock step
+  // (ablation), 100 = ping-pong with full-line A requests; default: the best the shape allows
+  const int v = tuning(TUNE_I8_VARIANT);
+  if (mfma_i8_pp_at_serves(p) && v != 0) return launch_i8_pp<0, true>(s, p);  // K x N A on the ping-pong schedule
+  if (mfma_i8_pp2_serves(p) && (v < 0 || v == 200)) return launch_i8_pp2s(s, p);   // 16x16x64 matrix instruction: +7.6 % (profiles/r03e_*)
+  if (mfma_i8_pp2_serves(p) && v == 100) return launch_i8_pp2(s, p);
+  if (mfma_i8_pp_serves(p) && v != 0) return v == 12 ? launch_i8_pp<2>(s, p) : launch_i8_pp<0>(s, p);
+  using G = GeoI8;
+  const unsigned tiles_n = (p.n + G::BM - 1) / G::BM, tiles_m = (p.m + G::BN - 1) / G::BN;
+  static unsigned long long configured = 0, configured_at = 0;
+  if (p.a_transposed) {
+    if (int e = ensure_dynamic_lds((const void *)mfma_i8_kernel<true>, G::LDS_BYTES, configured_at)) return e;
+    hipLaunchKernelGGL(mfma_i8_kernel<true>, dim3(tiles_n * tiles_m), dim3(G::THREADS), G::LDS_BYTES, s,
+                       (const signed char *)p.a, (const signed char *)p.b, (signed char *)p.c, p.n, p.k, p.m, tiles_n,
+                       tiles_m, band_rows());
+    return (int)hipGetLastError();
   }
+  if (int e = ensure_dynamic_lds((const void *)mfma_i8_kernel<false>, G::LDS_BYTES, configured)) return e;
+  hipLaunchKernelGGL(mfma_i8_kernel<false>, dim3(tiles_n * tiles_m), dim3(G::THREADS), G::LDS_BYTES, s,
+                     (const signed char *)p.a, (const signed char *)p.b, (signed char *)p.c, p.n, p.k, p.m, tiles_n,
+                     tiles_m, band_rows());
+  return (int)hipGetLastError();
 }
 
 }  // namespace mm

@@ -55,6 +55,20 @@ def run_pass(counters, what, size, workdir, idx):
     return out
 
 
+def dispatched_kernel_name(what, size, variant):
+    """mm_kernel_name() of the launch the passes profile (asked in a child process: the knob is process state)."""
+    table = {"f32": ("float", "Multiply", "Add", "f32_variant", 0), "f16": ("half", "Multiply", "Add", "f16_variant", 0),
+             "f64": ("double", "Multiply", "Add", "f64_variant", 0), "uint8": ("uint8_t", "Multiply", "Add", "i8_variant", 0),
+             "minplus": ("float", "Add", "Min", "valu_variant", 0), "split": ("float", "Multiply", "Add", "split_variant", 2)}
+    dtype, mp, rd, knob, path = table[what]
+    code = ("import gemm_hls_amd as g\n"
+            f"v = {variant!r}\n"
+            f"if v is not None: g.set_tuning({knob!r}, v)\n"
+            f"print(g.kernel_name(g.make_config({dtype!r}, {mp!r}, {rd!r}, {path}), {size}, {size}, {size}))\n")
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True)
+    return r.stdout.strip().splitlines()[-1] if r.returncode == 0 and r.stdout.strip() else None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("what", choices=list(KERNEL))
@@ -65,7 +79,8 @@ def main():
     args = ap.parse_args()
     global VARIANT
     VARIANT = args.variant
-    res = {"kernel": KERNEL[args.what], "variant": args.variant, "size": args.size, "passes": []}
+    res = {"kernel": KERNEL[args.what], "kernel_name": dispatched_kernel_name(args.what, args.size, args.variant),
+           "variant": args.variant, "size": args.size, "passes": []}
     flat = {}
     for i, p in enumerate(PASSES):
         r = run_pass(p, args.what, args.size, os.path.join(args.workdir, args.what), i)

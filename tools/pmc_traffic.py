@@ -53,6 +53,20 @@ def run_pass(counter, size, workdir, what="f32", variant=None):
     return vals
 
 
+def dispatched_kernel_name(what, size, variant):
+    """mm_kernel_name() of the launch the passes profile (asked in a child process: the knob is process state)."""
+    table = {"f32": ("float", "Multiply", "Add", "f32_variant", 0), "f16": ("half", "Multiply", "Add", "f16_variant", 0),
+             "f64": ("double", "Multiply", "Add", "f64_variant", 0), "uint8": ("uint8_t", "Multiply", "Add", "i8_variant", 0),
+             "minplus": ("float", "Add", "Min", "valu_variant", 0), "split": ("float", "Multiply", "Add", "split_variant", 2)}
+    dtype, mp, rd, knob, path = table[what]
+    code = ("import gemm_hls_amd as g\n"
+            f"v = {variant!r}\n"
+            f"if v is not None: g.set_tuning({knob!r}, v)\n"
+            f"print(g.kernel_name(g.make_config({dtype!r}, {mp!r}, {rd!r}, {path}), {size}, {size}, {size}))\n")
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True)
+    return r.stdout.strip().splitlines()[-1] if r.returncode == 0 and r.stdout.strip() else None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--size", type=int, default=16384)
@@ -68,7 +82,7 @@ def main():
     fetch_kib = sum(fetch) / len(fetch)
     write_kib = sum(write) / len(write)
     res = {
-        "kernel": WHAT[args.what][0], "workload": {"f32": "float"}.get(args.what, args.what), "variant": args.variant,
+        "kernel": WHAT[args.what][0], "kernel_name": dispatched_kernel_name(args.what, n, args.variant), "workload": {"f32": "float"}.get(args.what, args.what), "variant": args.variant,
         "shape": [n, n, n], "launches_profiled": len(fetch),
         "FETCH_SIZE_KiB_raw_per_launch": fetch_kib, "WRITE_SIZE_KiB_raw_per_launch": write_kib,
         "fetch_bytes_corrected": 2.0 * fetch_kib * 1024.0,  # gfx950: 128-B requests tallied as 64 B

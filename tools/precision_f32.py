@@ -11,7 +11,8 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
-import gemm_hls_amd as g  # noqa: E402
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _lib import g  # noqa: E402  (MM_LIB=lab selects the lab build)
 
 
 def main():

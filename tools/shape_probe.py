@@ -7,7 +7,8 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import gemm_hls_amd as g  # noqa: E402
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _lib import g  # noqa: E402  (MM_LIB=lab selects the lab build)
 
 KNOB = {"float": "f32_variant", "double": "f64_variant", "half": "f16_variant", "uint8_t": "i8_variant"}
 

@@ -6,7 +6,7 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import sweep  # noqa: E402
-import gemm_hls_amd as g  # noqa: E402
+from _lib import g  # noqa: E402  (MM_LIB=lab selects the lab build)
 
 sizes = [512, 1024, 1536, 2048, 3072, 4096, 5120, 6144, 8192, 12288, 16384]
 print(f"{'size':>6}  {'adaptive kernel':38s} {'TF':>7}   {'fixed 256x256 TF':>16}")

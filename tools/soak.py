@@ -18,7 +18,8 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
-import gemm_hls_amd as g  # noqa: E402
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _lib import g  # noqa: E402  (MM_LIB=lab selects the lab build)
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--scale", type=int, default=1)
@@ -33,8 +34,10 @@ nb = torch.rand((2048, 2048), device=dev)
 #      label          dtype      ops                  torch dtype     n     reps  knob          other variant   [path]
 CASES = [
     ("float split",  "float",   ("Multiply", "Add"), torch.float32, 8300, 100, "split_variant", 128, g.PATH_SPLIT),  # K = 8300: one flush + a ragged last slab
-    ("float",        "float",   ("Multiply", "Add"), torch.float32, 8192, 60, "f32_variant", 24),    # 24: round-1 schedule of the 256x256 kernel
-    ("half",         "half",    ("Multiply", "Add"), torch.float16, 16384, 150, "f16_variant", 0),
+    ("float",        "float",   ("Multiply", "Add"), torch.float32, 8192, 60, "f32_variant", 8),     # 8: the 256 x 256 / 8-wavefront geometry (default: 128 x 256 x 2)
+    # the default half kernel runs the 16x16x32 instruction; its cross-check (100) the 32x32x16 one: same products, a different
+    # fp32 summation order inside an MFMA -> equal up to the last binary16 bit in a few elements, never more
+    ("half",         "half",    ("Multiply", "Add"), torch.float16, 16384, 150, "f16_variant", 100),
     ("half K%64=32", "half",    ("Multiply", "Add"), torch.float16, 8224, 100, "f16_variant", 0),    # plain ping-pong (K % 64 != 0)
     ("double",       "double",  ("Multiply", "Add"), torch.float64, 4096, 40, "f64_variant", 2),     # 2: round-1 schedule
     ("uint8_t",      "uint8_t", ("Multiply", "Add"), torch.uint8, 16384, 150, "i8_variant", 0),
@@ -65,8 +68,13 @@ for label, dtype, ops, tdt, n, reps, knob, other, *rest in CASES:
         g.set_tuning(knob, -1)
         torch.cuda.synchronize()
         same_as_other = bool(torch.equal(alt.view(torch.uint8), ref.view(torch.uint8)))
-        if True:
-            assert same_as_other, f"{label}: differs from the independent schedule (variant {other})"
+        if not same_as_other and dtype == "half" and other == 100:
+            d = (alt.view(torch.int16).to(torch.int32) - ref.view(torch.int16).to(torch.int32)).abs()
+            frac = float((d != 0).float().mean())
+            assert int(d.max()) <= 1 and frac < 0.02, f"{label}: {int(d.max())} ulp apart, {100 * frac:.2f} % of elements"
+            same_as_other = True
+            label = f"{label} (<=1ulp {100 * frac:.2f}%)"
+        assert same_as_other, f"{label}: differs from the independent schedule (variant {other})"
     bad = 0
     t0 = time.perf_counter()
     for i in range(reps):
@@ -79,7 +87,7 @@ for label, dtype, ops, tdt, n, reps, knob, other, *rest in CASES:
         if not torch.equal(c.view(torch.uint8), ref.view(torch.uint8)):
             bad += 1
     torch.cuda.synchronize()
-    print(f"{label:16s} {name:26s} {rows}x{n}x{n}: {reps} launches, {bad} differing results, "
+    print(f"{label:16s} {name:36s} {rows}x{n}x{n}: {reps} launches, {bad} differing results, "
           f"equal to independent schedule: {same_as_other}, {time.perf_counter()-t0:.1f} s", flush=True)
     assert bad == 0
 print("soak ok")

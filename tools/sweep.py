@@ -10,7 +10,8 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import gemm_hls_amd as g  # noqa: E402
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _lib import g  # noqa: E402  (MM_LIB=lab selects the lab build)
 
 PEAK = {"float": 157.3, "double": 78.6, "half": 2500.0}
 
