@@ -156,6 +156,9 @@ def attach_replayed(roofline, kernel_name, shape):
         roofline["traffic_note"] = (f"no committed PMC file names kernel {kernel_name!r} at {list(shape)}: traffic and MFMA "
                                     "utilisation not reported rather than replayed from another kernel")
         return roofline
+    if roofline.get("bound") != "mfma":            # a VALU kernel has no MFMA utilisation to report
+        for key in ("mfma_util_pct", "mfma_util_source"):
+            rc.pop(key, None)
     roofline.update(rc)
     if "traffic" in rc:
         roofline["achieved_fabric_GBps"] = round(rc["traffic"] / (1e-3 * roofline["avg_launch_ms"]) / 1e9, 1)
