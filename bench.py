@@ -47,6 +47,9 @@ WORKLOADS = {
     "half": ("half", "Multiply", "Add", 32768, "mfma", 2500.0),
     "double": ("double", "Multiply", "Add", 16384, "mfma", 78.6),
     "minplus": ("float", "Add", "Min", 8192, "valu", 78.6),
+    # the same semiring on an 8-byte Data_t (round 3: the DMA-staged VALU kernel serves every element size).  fp64 VALU
+    # instructions issue at half the fp32 rate: 1024 SIMDs x 16 lanes/clk x 2.4 GHz = 39.3 T lane-ops/s, add and min = 2 ops
+    "minplus_f64": ("double", "Add", "Min", 8192, "valu", 39.3),
     "uint8": ("uint8_t", "Multiply", "Add", 32768, "mfma", 5000.0),
     # MM_PATH_SPLIT (opt-in): the same fp32 problem on the bf16 matrix cores, six bf16 MFMAs per 16-deep fp32
     # multiply-add block -> the roof for ALGORITHMIC fp32 flops is the bf16 dense peak / 6
@@ -220,7 +223,8 @@ def roofline_obj(dtype, roof, peak, rows, k, m, launch_ms):
 def extra_workloads(g, torch, dev, local_rank, steps=5):
     """The other single-GPU BASELINE configs, a few steps each, in the same process."""
     out = []
-    jobs = [("half", None), ("double", None), ("minplus", None), ("uint8", None), ("float", C5A_ROWS), ("float_split", None)]
+    jobs = [("half", None), ("double", None), ("minplus", None), ("minplus_f64", None), ("uint8", None), ("float", C5A_ROWS),
+            ("float_split", None)]
     for key, rows_override in jobs:
         dtype, map_op, reduce_op, size, roof, peak = WORKLOADS[key]
         rows = rows_override or size

@@ -157,6 +157,10 @@ def build(verbose=True):
     exe("RunHardware_transposedA_float.exe", "RunHardware.cpp", defs("float", "Multiply", "Add", transposed=True))
     exe("RunHardware_transposedA_int.exe", "RunHardware.cpp", defs("int", "Multiply", "Add", transposed=True))
     exe("RunHardware_power.exe", "RunHardware.cpp", defs(dt, mp, rd, power=True))
+    # the reference's tile knob (CMakeLists.txt:18-20): a build pinned to the 256 x 256 resident tile
+    pin = ["-DMM_MEMORY_TILE_SIZE_N=256", "-DMM_MEMORY_TILE_SIZE_M=256"]
+    exe("RunHardware_tile256x256.exe", "RunHardware.cpp", defs(dt, mp, rd) + pin)
+    exe("PrintSpecifications_tile256x256.exe", "PrintSpecifications.cpp", defs(dt, mp, rd) + pin)
     # kernel shims + the CTest binary bound to them: dynamic, static (3-pointer symbol) and K x N A
     shim("libmmkernel.so", defs(dt, mp, rd))
     shim(f"libmmkernel_static_float_{tag}.so", defs(dt, mp, rd, static))

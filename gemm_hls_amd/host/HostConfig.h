@@ -62,6 +62,30 @@ static_assert(kSizeK % kMemoryWidthK == 0, "K must be divisable by memory width.
 
 namespace mmhost {
 
+// -DMM_MEMORY_TILE_SIZE_N=<BM> -DMM_MEMORY_TILE_SIZE_M=<BN> (the reference's build knob for the resident output tile,
+// CMakeLists.txt:18-20 -> include/Config.h.in:19-23): pins this binary's kernel to a BM x BN tile WHEN the library has
+// that geometry for the configuration -- float 128x256 / 256x256 / 128x128, double 256x128 / 128x128, half 256x256 /
+// 128x256.  Any other value (e.g. the reference's 512x512) leaves the per-problem choice to the library, which is
+// also what a build without the two macros does.  Returns the name of the knob it set, or nullptr.
+inline const char *ApplyBuildTimeTile() {
+#if defined(MM_MEMORY_TILE_SIZE_N) && defined(MM_MEMORY_TILE_SIZE_M)
+  constexpr int bm = MM_MEMORY_TILE_SIZE_N, bn = MM_MEMORY_TILE_SIZE_M;
+  struct Pin { int bm, bn; const char *knob; int value; };
+  constexpr bool f32 = std::is_same<MM_DATA_TYPE, float>::value, f64 = std::is_same<MM_DATA_TYPE, double>::value,
+                 f16 = std::is_same<MM_DATA_TYPE, _Float16>::value;
+  const Pin pins[] = {{128, 256, f32 ? "f32_variant" : nullptr, 33}, {256, 256, f32 ? "f32_variant" : nullptr, 8},
+                      {128, 128, f32 ? "f32_variant" : nullptr, 35}, {256, 128, f64 ? "f64_variant" : nullptr, 0},
+                      {128, 128, f64 ? "f64_variant" : nullptr, 1},  {256, 256, f16 ? "f16_variant" : nullptr, -1},
+                      {128, 256, f16 ? "f16_variant" : nullptr, 4}};
+  for (const Pin &p : pins)
+    if (p.knob && p.bm == bm && p.bn == bn) {
+      if (p.value >= 0) mm_tuning_set(p.knob, p.value);
+      return p.knob;
+    }
+#endif
+  return nullptr;
+}
+
 template <typename T> struct DTypeOf;
 #define MM_DTYPE_OF(T, E) template <> struct DTypeOf<T> { static constexpr mm_dtype_t value = E; };
 MM_DTYPE_OF(float, MM_DTYPE_F32)

@@ -27,6 +27,8 @@
 
 namespace {
 void Run(const void *a, const void *b, void *c, unsigned size_n, unsigned size_k, unsigned size_m) {
+  static const char *const pinned = mmhost::ApplyBuildTimeTile();   // once: -DMM_MEMORY_TILE_SIZE_N/M
+  (void)pinned;
   const mm_config_t cfg = {mmhost::DTypeOf<Data_t>::value, OperatorMap::code, OperatorReduce::code, (mm_path_t)MM_DEFAULT_PATH,
                            kTransposedA ? MM_A_TRANSPOSED : MM_A_ROW_MAJOR};
   if (mm_gemm_host(&cfg, a, b, c, size_n, size_k, size_m) != MM_OK) {

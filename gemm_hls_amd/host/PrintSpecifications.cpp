@@ -16,30 +16,53 @@
 
 #include "HostConfig.h"
 
-static void PrintUsage(char **argv) {
-#ifndef MM_DYNAMIC_SIZES
-  std::cerr << "Usage: " << argv[0] << " [<routed frequency>]\n" << std::flush;
+namespace {
+
+// What the command line asks for.  The reference's grammar (src/PrintSpecifications.cpp:16-36): three sizes first when
+// the build has dynamic sizes, then an optional frequency in MHz; anything else prints the usage line and exits 1.
+struct Request {
+  unsigned n = 0, k = 0, m = 0;
+  bool has_frequency = false;
+  float frequency_mhz = 0;
+};
+
+#ifdef MM_DYNAMIC_SIZES
+constexpr int kSizeArgs = 3;
+constexpr const char *kUsageTail = " N K M [<routed_frequency>]\n";
 #else
-  std::cerr << "Usage: " << argv[0] << " N K M [<routed_frequency>]\n" << std::flush;
+constexpr int kSizeArgs = 0;
+constexpr const char *kUsageTail = " [<routed frequency>]\n";
 #endif
+
+bool Parse(int argc, char **argv, Request *req) {
+  const int given = argc - 1;
+  if (given < kSizeArgs || given > kSizeArgs + 1) return false;
+#ifdef MM_DYNAMIC_SIZES
+  req->n = std::stoul(argv[1]);
+  req->k = std::stoul(argv[2]);
+  req->m = std::stoul(argv[3]);
+#else
+  req->n = kSizeN;
+  req->k = kSizeK;
+  req->m = kSizeM;
+#endif
+  if (given == kSizeArgs + 1) {
+    req->has_frequency = true;
+    req->frequency_mhz = std::stof(argv[kSizeArgs + 1]);
+  }
+  return true;
 }
 
+}  // namespace
+
 int main(int argc, char **argv) {
-#ifdef MM_DYNAMIC_SIZES
-  if (argc > 5 || argc < 4) {
-    PrintUsage(argv);
+  Request req;
+  if (!Parse(argc, argv, &req)) {
+    std::cerr << "Usage: " << argv[0] << kUsageTail << std::flush;
     return 1;
   }
-  const unsigned size_n = std::stoul(argv[1]), size_k = std::stoul(argv[2]), size_m = std::stoul(argv[3]);
-  int next_arg = 4;
-#else
-  if (argc > 2) {
-    PrintUsage(argv);
-    return 1;
-  }
-  constexpr unsigned size_n = kSizeN, size_k = kSizeK, size_m = kSizeM;
-  int next_arg = 1;
-#endif
+  mmhost::ApplyBuildTimeTile();
+  const unsigned size_n = req.n, size_k = req.k, size_m = req.m;
   const mm_config_t cfg = {mmhost::DTypeOf<Data_t>::value, OperatorMap::code, OperatorReduce::code, MM_PATH_AUTO,
                            MM_A_ROW_MAJOR};
   mm_kernel_info_t info;
@@ -47,8 +70,7 @@ int main(int argc, char **argv) {
     std::cerr << mm_last_error() << "\n";
     return 1;
   }
-  float frequency = info.max_clock_mhz;
-  if (argc > next_arg) frequency = std::stof(argv[next_arg]);
+  const float frequency = req.has_frequency ? req.frequency_mhz : (float)info.max_clock_mhz;
 
   const unsigned long long nOps = 2ull * size_n * size_k * size_m;
   const unsigned long long tilesN = (size_n + info.tile_n - 1) / info.tile_n, tilesM = (size_m + info.tile_m - 1) / info.tile_m;

@@ -61,6 +61,7 @@ struct DeviceBuffer {
 }  // namespace
 
 int main(int argc, char **argv) {
+  mmhost::ApplyBuildTimeTile();   // -DMM_MEMORY_TILE_SIZE_N/M: pin the resident tile if the library has that geometry
   bool emulation = false;
   bool verify = true;
 #ifdef MM_DYNAMIC_SIZES

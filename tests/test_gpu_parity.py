@@ -361,6 +361,32 @@ def test_valu_tile_dma_staged_kernel_equals_synchronous_kernel_and_naive(dtype, 
     g.set_tuning("valu_variant", -1)
 
 
+@pytest.mark.parametrize("dtype,mp,rd", [("double", "Add", "Min"), ("double", "Min", "Max"), ("long", "Multiply", "Add"),
+                                          ("unsigned long", "Add", "Max"), ("half", "Add", "Min"), ("half", "Max", "Min"),
+                                          ("int16_t", "Multiply", "Add"), ("uint16_t", "Add", "Min"), ("int8_t", "Add", "Max"),
+                                          ("uint8_t", "Min", "Max"), ("uint8_t", "Add", "Min")], ids=lambda x: str(x))
+@pytest.mark.parametrize("shape", [(513, 528, 528), (129, 80, 272), (300, 48, 144), (257, 608, 528), (1, 64, 16), (700, 16, 64),
+                                   (130, 1040, 128)], ids=lambda s: "x".join(map(str, s)))
+def test_valu_tile_dma_staged_kernel_serves_every_element_size(dtype, mp, rd, shape):
+    """Round 3: the DMA-staged VALU kernel for 8-, 2- and 1-byte types too (slab depth 64 / sizeof(T), same byte
+    geometry): the reference's ProcessingElement runs any Data_t at full rate (kernel/Compute.cpp:120-139).  Shapes
+    include partial last slabs for every slab depth (8 / 32 / 64 k) and ragged N; K and M are multiples of 16 so that
+    every type's 16-byte-chunk requirement holds.  Same bits as the synchronous kernel and as Naive."""
+    n, k, m = shape
+    a, b = _oracle.fill(dtype, n, k, m)
+    if dtype in ("double", "half"):
+        rng = np.random.default_rng(n + k + m)
+        a = (a * rng.choice([-1.0, 1.0], size=a.shape)).astype(a.dtype)
+        b = (b - 5.5).astype(b.dtype)
+    want = _oracle.naive(dtype, mp, rd, a, b)
+    assert g.kernel_name(g.make_config(dtype, mp, rd), n, k, m) == "valu_tile"
+    for variant in (-1, 0):
+        g.set_tuning("valu_variant", variant)
+        c, _ = g.matmul_capi(a, b, dtype, mp, rd)
+        assert np.array_equal(c.view(np.uint8), want.view(np.uint8)), (variant, dtype, mp, rd, shape)
+    g.set_tuning("valu_variant", -1)
+
+
 def _golden_cases():
     for path in sorted(glob.glob(os.path.join(GOLD, "ref_*_*x*x*.npz"))):
         stem = os.path.basename(path)[4:-4]
