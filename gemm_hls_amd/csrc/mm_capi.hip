@@ -87,9 +87,9 @@ mm_config_t default_cfg() {
 std::once_flag g_tuning_once;
 std::atomic<int> g_tuning[mm::TUNE_COUNT];
 const char *const kTuneName[mm::TUNE_COUNT] = {"f32_variant", "f64_variant", "f16_variant", "i8_variant", "band_rows",
-                                               "valu_variant", "split_variant", "ablations"};
+                                               "valu_variant", "split_variant", "f32_splitk", "ablations"};
 const char *const kTuneEnv[mm::TUNE_COUNT] = {"MM_F32_VARIANT", "MM_F64_VARIANT", "MM_F16_VARIANT", "MM_I8_VARIANT",
-                                              "MM_BAND_ROWS", "MM_VALU_VARIANT", "MM_SPLIT_VARIANT", "MM_ABLATIONS"};
+                                              "MM_BAND_ROWS", "MM_VALU_VARIANT", "MM_SPLIT_VARIANT", "MM_F32_SPLITK", "MM_ABLATIONS"};
 void tuning_init() {
   for (int i = 0; i < mm::TUNE_COUNT; ++i) {
     const char *e = getenv(kTuneEnv[i]);
@@ -190,6 +190,35 @@ struct Event {
 
 }  // namespace
 
+// One library-owned memory pool per device for stream-ordered workspace (the packed planes of MM_PATH_SPLIT, the
+// partial tiles of the fp32 split-K launches): freed workspace stays cached between launches (release threshold
+// "never") without touching the process's default pool, whose settings belong to the application.
+// mm_release_workspace() trims it.
+static hipMemPool_t g_workspace_pool[64] = {};
+static std::mutex g_workspace_mu;
+int mm::workspace_pool(int dev, hipMemPool_t *out) {
+  std::lock_guard<std::mutex> lock(g_workspace_mu);
+  hipMemPool_t &pool = g_workspace_pool[dev & 63];
+  if (!pool) {
+    hipMemPoolProps props = {};
+    props.allocType = hipMemAllocationTypePinned;
+    props.handleTypes = hipMemHandleTypeNone;
+    props.location.type = hipMemLocationTypeDevice;
+    props.location.id = dev;
+    hipError_t e = hipMemPoolCreate(&pool, &props);
+    if (e != hipSuccess) { pool = nullptr; return (int)e; }
+    unsigned long long keep = ~0ull;
+    if ((e = hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep)) != hipSuccess) return (int)e;
+  }
+  *out = pool;
+  return 0;
+}
+int mm::workspace_release(int dev) {
+  std::lock_guard<std::mutex> lock(g_workspace_mu);
+  hipMemPool_t pool = g_workspace_pool[dev & 63];
+  return pool ? (int)hipMemPoolTrimTo(pool, 0) : 0;
+}
+
 int mm::tuning(mm::Tunable t) {
   std::call_once(g_tuning_once, tuning_init);
   return g_tuning[t].load(std::memory_order_relaxed);
@@ -245,7 +274,7 @@ int mm_release_workspace(int device) {
   if (rc) return rc;
   MM_HIP(hipSetDevice(device));
   MM_HIP(hipDeviceSynchronize());   // stream-ordered frees are complete: everything the pool holds is reclaimable
-  MM_HIP((hipError_t)mm::mfma_f32_split_release(device));
+  MM_HIP((hipError_t)mm::workspace_release(device));
   return MM_OK;
 }
 
@@ -394,7 +423,7 @@ int mm_gemm_multi_device(int device_count, const mm_config_t *cfg, const void *a
     Dev &d = devs[g];
     if (!d.rows) continue;
     MM_HIP_MD(hipSetDevice(g));
-    mm::Problem warm{d.a, d.b, d.c, d.rows, k, m, false};
+    mm::Problem warm{d.a, d.b, d.c, d.rows, k, m, false, n};
     rc = dispatch(d.s, *cfg, warm);
     if (rc) { cleanup(); return rc; }
   }
@@ -405,7 +434,7 @@ int mm_gemm_multi_device(int device_count, const mm_config_t *cfg, const void *a
     Dev &d = devs[g];
     if (!d.rows) continue;
     MM_HIP_MD(hipSetDevice(g));
-    mm::Problem p{d.a, d.b, d.c, d.rows, k, m, false};
+    mm::Problem p{d.a, d.b, d.c, d.rows, k, m, false, n};   // a row slab of the n-row job
     rc = dispatch(d.s, *cfg, p);
     if (rc) { cleanup(); return rc; }
   }
@@ -474,7 +503,7 @@ static int mm_run_host_pointers(const mm_config_t &cfg, const void *a, const voi
     char *a_dst = (char *)ad + (cfg.layout_a == MM_A_ROW_MAJOR ? (size_t)r0 * k * es : 0);
     MM_HIP_HP(hipMemcpy(a_dst, a_src, (size_t)(slabs == 1 ? n : rows) * k * es, hipMemcpyHostToDevice));
     mm::Problem p{a_dst, bd, (char *)cd + (size_t)r0 * m * es, slabs == 1 ? n : rows, k, m,
-                  cfg.layout_a == MM_A_TRANSPOSED};
+                  cfg.layout_a == MM_A_TRANSPOSED, n};   // a row slab of the n-row job
     rc = dispatch(stream, cfg, p);
     if (rc) { cleanup(); return rc; }
     hipEvent_t e;
@@ -521,7 +550,16 @@ const char *mm_kernel_name(const mm_config_t *cfg, unsigned n, unsigned k, unsig
   mm::Problem p{nullptr, nullptr, nullptr, n, k, m, cfg->layout_a == MM_A_TRANSPOSED};
   switch (choose(*cfg, p)) {
     // every family answers through the same resolver its launcher uses, so the name IS the kernel that runs
-    case FAM_MFMA_F32: return f32_variant_for(p) < 0 ? "unsupported" : mm::mfma_f32_name(f32_variant_for(p));
+    case FAM_MFMA_F32: {
+      const int v = f32_variant_for(p);
+      if (v < 0) return "unsupported";
+      static const char *const split_names[] = {nullptr, nullptr, "mfma_f32_128x128x32_w4x2_splitk2", "mfma_f32_128x128x32_w4x2_splitk3",
+                                                "mfma_f32_128x128x32_w4x2_splitk4", "mfma_f32_128x128x32_w4x2_splitk5",
+                                                "mfma_f32_128x128x32_w4x2_splitk6", "mfma_f32_128x128x32_w4x2_splitk7",
+                                                "mfma_f32_128x128x32_w4x2_splitk8"};
+      const int splits = mm::mfma_f32_splitk(p, v);
+      return splits > 1 ? split_names[splits] : mm::mfma_f32_name(v);
+    }
     case FAM_MFMA_F64: return mm::mfma_f64_name(p);
     case FAM_MFMA_F16: return mm::mfma_f16_name(p);
     case FAM_MFMA_I8: return mm::mfma_i8_name(p);

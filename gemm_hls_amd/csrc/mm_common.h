@@ -73,6 +73,10 @@ struct Problem {
   void *c;         // N x M row-major, pure output
   unsigned n, k, m;
   bool a_transposed;
+  // rows of the whole job when this launch is one row slab of it (the host-pointer pipeline, the N-split over GPUs);
+  // 0 = n.  Decisions that change the summation order (split-K) are taken on the whole job, so that a row's bits do
+  // not depend on how the rows were dealt out.
+  unsigned n_total = 0;
 };
 
 // Launchers (one translation unit each).  Return hipError_t as int; hipErrorNotSupported (801)
@@ -89,7 +93,9 @@ int launch_mfma_f32_split(hipStream_t s, const Problem &p, int variant);  // MM_
 bool mfma_f32_split_serves(const Problem &p);
 size_t mfma_f32_split_workspace_bytes(const Problem &p);
 int mfma_f32_split_tile(const Problem &p, int variant);  // 256 or 128
-int mfma_f32_split_release(int device);                  // trims the library-owned workspace pool of `device`
+int workspace_pool(int device, hipMemPool_t *pool);      // the library-owned, stream-ordered workspace pool of `device` (mm_capi.hip)
+int workspace_release(int device);                       // hands its cached memory back to the driver
+int mfma_f32_splitk(const Problem &p, int variant);      // K chunks the fp32 MFMA launcher uses for (problem, resolved variant)
 bool mfma_f32_serves(const Problem &p);
 bool mfma_f64_serves(const Problem &p);
 bool mfma_f16_serves(const Problem &p);
@@ -134,6 +140,7 @@ enum Tunable {
   TUNE_BAND_ROWS,        // MM_BAND_ROWS    tile-rows per rasterisation band
   TUNE_VALU_VARIANT,     // MM_VALU_VARIANT 0 = synchronous valu_tile kernel, else (default) the DMA-staged one
   TUNE_SPLIT_VARIANT,    // MM_SPLIT_VARIANT schedule / product count of the MM_PATH_SPLIT kernel (mm_mfma_f32_split.hip)
+  TUNE_F32_SPLITK,       // MM_F32_SPLITK   fp32 MFMA path: -1 by shape (small problems only), 1 never, 2..8 that many K chunks
   TUNE_ABLATIONS,        // MM_ABLATIONS    1 = allow the variants that skip work on purpose (power breakdown
                          //                 measurements; they produce WRONG results and are refused otherwise)
   TUNE_COUNT

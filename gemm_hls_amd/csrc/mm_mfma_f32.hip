@@ -114,7 +114,7 @@ __global__ __launch_bounds__(G::THREADS, G::MIN_WAVES) void mfma_f32_kernel(cons
                                                               float *__restrict__ C, unsigned N,
                                                               unsigned K, unsigned M,
                                                               unsigned tiles_n, unsigned tiles_m,
-                                                              unsigned kBand) {
+                                                              unsigned kBand, unsigned kChunk, float *__restrict__ partials) {
   constexpr int TM = G::TM, TN = G::TN, BK = G::BK, NS = G::NS, CPR = G::CPR;
   constexpr bool TWO_LEVEL = G::CHAIN == Chain::TwoLevel, FLUSH = G::CHAIN == Chain::FlushIntoC;
   constexpr bool PIPELINED = G::READS == Reads::Pipelined, SDMA = G::DMA == Dma::ScalarBase;
@@ -125,9 +125,23 @@ __global__ __launch_bounds__(G::THREADS, G::MIN_WAVES) void mfma_f32_kernel(cons
   const unsigned wm = wave / G::WN, wn = wave % G::WN;
   const unsigned lo = lane & 31u, hi = lane >> 5;
 
-  // ---- workgroup -> output tile: XCD-contiguous chunks, then bands of kBand tile-rows ------------
+  // ---- split-K launches (small problems, see mfma_f32_splitk): the grid holds `splits` copies of the tile grid; copy s
+  //      multiplies the k range [s * kChunk, min(K, (s+1) * kChunk)) into its own N x M plane of `partials`, and a second
+  //      kernel adds the planes in ascending s (deterministic).  lda = the row stride of A, which no longer equals K.
   const unsigned nwg = tiles_n * tiles_m;
-  const unsigned lin = xcd_remap(blockIdx.x, nwg);
+  const unsigned lda = K;
+  unsigned bid = blockIdx.x;
+  if (kChunk) {   // wavefront-uniform
+    const unsigned split = bid / nwg;
+    bid -= split * nwg;
+    const unsigned kbeg = split * kChunk;
+    A += AT ? (size_t)kbeg * N : (size_t)kbeg;
+    B += (size_t)kbeg * M;
+    C = partials + (size_t)split * N * M;
+    K = min(kChunk, K - kbeg);
+  }
+  // ---- workgroup -> output tile: XCD-contiguous chunks, then bands of kBand tile-rows ------------
+  const unsigned lin = xcd_remap(bid, nwg);
   const unsigned band = lin / (kBand * tiles_m), within = lin % (kBand * tiles_m);
   const unsigned rows_in_band = min(kBand, tiles_n - band * kBand);
   const unsigned tile_row = band * kBand + within % rows_in_band;
@@ -149,7 +163,7 @@ __global__ __launch_bounds__(G::THREADS, G::MIN_WAVES) void mfma_f32_kernel(cons
     } else {
       const unsigned row = slot / CPR, pc = slot % CPR;
       a_kchunk[i] = pc ^ ((row >> G::SWZ_SHIFT) & (CPR - 1));
-      a_row_off[i] = (size_t)min(row0 + row, N - 1) * K;
+      a_row_off[i] = (size_t)min(row0 + row, N - 1) * lda;
     }
   }
   unsigned b_krow[G::LB];
@@ -187,7 +201,7 @@ __global__ __launch_bounds__(G::THREADS, G::MIN_WAVES) void mfma_f32_kernel(cons
     for (int i = 0; i < G::LA; ++i) {
       const unsigned slot = (wave + G::NW * i) * 64 + lane, row = slot / CPR;
       if (AT) voa[i] = a_kchunk[i] * N * 4u + ((unsigned)a_row_off[i] - row0) * 4u;   // K x N: k-row, clamped column
-      else voa[i] = (min(row0 + row, N - 1) - row0) * K * 4u + a_kchunk[i] * 16u;
+      else voa[i] = (min(row0 + row, N - 1) - row0) * lda * 4u + a_kchunk[i] * 16u;
     }
 #pragma unroll
     for (int i = 0; i < G::LB; ++i) vob[i] = b_krow[i] * M * 4u + (b_col[i] - col0) * 4u;
@@ -198,7 +212,7 @@ __global__ __launch_bounds__(G::THREADS, G::MIN_WAVES) void mfma_f32_kernel(cons
     const bool is_a = i < G::LA;
     const int j = is_a ? i : i - G::LA;
     unsigned long long base = !is_a ? (unsigned long long)(B + (size_t)kc * M + col0)
-                              : AT ? (unsigned long long)(A + (size_t)kc * N + row0) : (unsigned long long)(A + (size_t)row0 * K + kc);
+                              : AT ? (unsigned long long)(A + (size_t)kc * N + row0) : (unsigned long long)(A + (size_t)row0 * lda + kc);
     const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)base), bhi = __builtin_amdgcn_readfirstlane((unsigned)(base >> 32));
     base = ((unsigned long long)bhi << 32) | blo;
     const unsigned la = lds_base + buf * G::STAGE_BYTES + (is_a ? 0 : G::A_BYTES) + (wave + G::NW * j) * 1024;
@@ -535,15 +549,50 @@ __global__ __launch_bounds__(G::THREADS, G::MIN_WAVES) void mfma_f32_kernel(cons
   if (FLUSH && flushed) write_tile(true); else write_tile(false);
 }
 
+// C = sum over s of partials[s], s ascending: the second kernel of a split-K launch (4 floats per thread)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restrict__ partials, float *__restrict__ C,
+                                                            size_t quads, unsigned splits) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= quads) return;
+  const f32x4 *src = (const f32x4 *)partials;
+  f32x4 acc = src[i];
+  for (unsigned s = 1; s < splits; ++s) acc += src[(size_t)s * quads + i];
+  ((f32x4 *)C)[i] = acc;
+}
+
 template <typename G, bool AT = false>
-int launch_geo(hipStream_t s, const Problem &p) {
+int launch_geo(hipStream_t s, const Problem &p, unsigned splits = 1) {
   const unsigned tiles_n = (p.n + G::BM - 1) / G::BM, tiles_m = (p.m + G::BN - 1) / G::BN;
   static unsigned long long configured = 0;
   if (int e = ensure_dynamic_lds((const void *)mfma_f32_kernel<G, AT>, G::LDS_BYTES, configured)) return e;
-  hipLaunchKernelGGL((mfma_f32_kernel<G, AT>), dim3(tiles_n * tiles_m), dim3(G::THREADS), G::LDS_BYTES, s,
+  (void)hipGetLastError();   // a stale error of the application's own calls must not be reported as this launch's
+  if (splits <= 1) {
+    hipLaunchKernelGGL((mfma_f32_kernel<G, AT>), dim3(tiles_n * tiles_m), dim3(G::THREADS), G::LDS_BYTES, s,
+                       (const float *)p.a, (const float *)p.b, (float *)p.c, p.n, p.k, p.m, tiles_n, tiles_m,
+                       band_rows(G::BM, G::BN, G::MIN_WAVES), 0u, (float *)nullptr);
+    return (int)hipGetLastError();
+  }
+  // split-K: `splits` planes of N x M partial sums from the library's stream-ordered pool, then the ordered reduction
+  const unsigned chunk = ((p.k + splits - 1) / splits + 31u) & ~31u;   // whole slabs of either depth
+  const size_t plane = (size_t)p.n * p.m;
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return (int)e;
+  hipMemPool_t pool = nullptr;
+  if (int rc = workspace_pool(dev, &pool)) return rc;
+  float *ws = nullptr;
+  if ((e = hipMallocFromPoolAsync((void **)&ws, plane * splits * sizeof(float), pool, s)) != hipSuccess) return (int)e;
+  hipLaunchKernelGGL((mfma_f32_kernel<G, AT>), dim3(tiles_n * tiles_m * splits), dim3(G::THREADS), G::LDS_BYTES, s,
                      (const float *)p.a, (const float *)p.b, (float *)p.c, p.n, p.k, p.m, tiles_n, tiles_m,
-                     band_rows(G::BM, G::BN, G::MIN_WAVES));
-  return (int)hipGetLastError();
+                     band_rows(G::BM, G::BN, G::MIN_WAVES), chunk, ws);
+  int rc = (int)hipGetLastError();
+  if (rc == 0) {
+    const size_t quads = plane / 4;   // M % 4 == 0
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, s, ws, (float *)p.c, quads, splits);
+    rc = (int)hipGetLastError();
+  }
+  const hipError_t f = hipFreeAsync(ws, s);
+  return rc ? rc : (int)f;
 }
 
 // The geometries of the product.  Every shipped geometry exists as a (ScalarBase, VectorAddress) pair with identical
@@ -610,6 +659,26 @@ int mfma_f32_resolve(const Problem &p, int variant) {
   return find_variant(variant) ? variant : -1;
 }
 
+// Split-K for problems that cannot fill the chip with whole tiles (1024^3 ran at 33 TF -- 64 tiles of
+// 128 x 128 for 512 workgroup slots).  Only the 128 x 128 geometry under the shape-adaptive pick splits: when its tiles
+// leave a quarter or more of the CUs without a workgroup (<= 192 tiles), K is cut into S = min(slots / tiles, K / 256, 8) chunks, the S copies of the tile grid run
+// side by side and a second kernel adds the S partial planes in ascending order -- deterministic, run to run and
+// whatever the placement, but a different summation order than the unsplit kernel (as accurate or better: shorter
+// chains).  f32_splitk: -1 this rule, 1 never, 2..8 that many chunks (still only for row-major A and variant 35).
+int mfma_f32_splitk(const Problem &p, int variant) {
+  if (p.a_transposed || variant != 35) return 1;
+  const int knob = tuning(TUNE_F32_SPLITK);
+  const unsigned rows = p.n_total ? p.n_total : p.n;   // of the whole job (Problem::n_total)
+  const unsigned long long tiles = (unsigned long long)((rows + 127) / 128) * ((p.m + 127) / 128);
+  unsigned s;
+  if (knob >= 1) s = (unsigned)knob;
+  else if (tuning(TUNE_F32_VARIANT) >= 0) s = 1;          // a pinned geometry is run as pinned
+  else s = tiles <= 192 ? (unsigned)(512 / tiles) : 1;   // 256 tiles already give every CU a workgroup (2048^3: 125 vs 112 TF split)
+  if (s > 8) s = 8;
+  while (s > 1 && p.k / s < 256) --s;                     // chunks of at least 256 k
+  return (int)s;
+}
+
 const char *mfma_f32_name(int v) {
   const VariantInfo *i = find_variant(v);
   return i ? i->name : "?";
@@ -635,7 +704,10 @@ int launch_mfma_f32(hipStream_t s, const Problem &p, int variant) {
   switch (v) {
     case 33: return sdma_fits(p, 16) ? launch_geo<T128x256>(s, p) : launch_geo<T128x256v>(s, p);
     case 8: return sdma_fits(p, 16) ? launch_geo<T256x256>(s, p) : launch_geo<T256x256v>(s, p);
-    case 35: return sdma_fits(p, 32) ? launch_geo<T128x128>(s, p) : launch_geo<T128x128v>(s, p);
+    case 35: {
+      const unsigned splits = (unsigned)mfma_f32_splitk(p, v);
+      return sdma_fits(p, 32) ? launch_geo<T128x128>(s, p, splits) : launch_geo<T128x128v>(s, p, splits);
+    }
     case 0: return launch_geo<X128x256x32_2lvl>(s, p);
     case 3: return launch_geo<X256x256_single>(s, p);
   }

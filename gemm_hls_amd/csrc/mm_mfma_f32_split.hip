@@ -474,32 +474,6 @@ size_t mfma_f32_split_workspace_bytes(const Problem &p) {
 }
 
 
-// One library-owned memory pool per device for the packed planes.
-static hipMemPool_t g_split_pool[64] = {};
-static int split_pool(int dev, hipMemPool_t *out) {
-  static std::mutex mu;
-  std::lock_guard<std::mutex> lock(mu);
-  hipMemPool_t &pool = g_split_pool[dev & 63];
-  if (!pool) {
-    hipMemPoolProps props = {};
-    props.allocType = hipMemAllocationTypePinned;
-    props.handleTypes = hipMemHandleTypeNone;
-    props.location.type = hipMemLocationTypeDevice;
-    props.location.id = dev;
-    hipError_t e = hipMemPoolCreate(&pool, &props);
-    if (e != hipSuccess) { pool = nullptr; return (int)e; }
-    unsigned long long keep = ~0ull;
-    if ((e = hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep)) != hipSuccess) return (int)e;
-  }
-  *out = pool;
-  return 0;
-}
-// mm_release_workspace(): hand the cached workspace of `dev` back to the driver (the caller has synchronised)
-int mfma_f32_split_release(int dev) {
-  hipMemPool_t pool = g_split_pool[dev & 63];
-  return pool ? (int)hipMemPoolTrimTo(pool, 0) : 0;
-}
-
 // variant (split_variant knob): -1 / 0 = default (6 products, ping-pong schedule, flush every 8256 k); otherwise a bit
 // mask: 1 first schedule of the round (one barrier per stage, fragment reads ahead of each MFMA group, s_setprio around
 // the group), 2 three products (planes 1 and 2 only), 4 no flush, 8 plain hipMalloc/hipFree workspace (diagnosis),
@@ -509,14 +483,12 @@ int launch_mfma_f32_split(hipStream_t s, const Problem &p, int variant) {
   const unsigned slabs = (p.k + 15) / 16;
   const unsigned blocks_a = (p.n + 255) / 256, blocks_b = (p.m + 255) / 256;
   const size_t a_bytes = (size_t)blocks_a * slabs * Packed::SLAB_BYTES, b_bytes = (size_t)blocks_b * slabs * Packed::SLAB_BYTES;
-  // The workspace comes from a pool this library owns (one per device, created on first use, release threshold
-  // "never"): freed workspace stays cached between launches without touching the process's default pool, whose
-  // settings belong to the application.  mm_release_workspace() trims it.
+  // The workspace comes from the pool this library owns (mm_capi.hip: workspace_pool).
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return (int)e;
   hipMemPool_t pool = nullptr;
-  if (int rc = split_pool(dev, &pool)) return rc;
+  if (int rc = workspace_pool(dev, &pool)) return rc;
   char *ws = nullptr;
   const int v = variant < 0 ? 0 : variant;
   if (v & 48) return kErrNotSupported;   // (ablation ids of the lab build)

@@ -27,10 +27,10 @@ SHAPES = [(513, 528, 528), (1, 16, 16), (37, 32, 48), (300, 64, 272), (129, 80, 
 @pytest.fixture(autouse=True)
 def _default_tuning():
     """Every test starts and ends on the library's own geometry choice (knobs are process-wide)."""
-    for knob in ("f32_variant", "f64_variant", "f16_variant", "i8_variant", "band_rows", "valu_variant"):
+    for knob in ("f32_variant", "f64_variant", "f16_variant", "i8_variant", "band_rows", "valu_variant", "f32_splitk"):
         g.set_tuning(knob, -1)
     yield
-    for knob in ("f32_variant", "f64_variant", "f16_variant", "i8_variant", "band_rows", "valu_variant"):
+    for knob in ("f32_variant", "f64_variant", "f16_variant", "i8_variant", "band_rows", "valu_variant", "f32_splitk"):
         g.set_tuning(knob, -1)
 
 
@@ -87,6 +87,38 @@ def test_f32_shipped_geometries_are_bit_identical_to_each_other(shape):
         assert np.max(np.abs(out[8] - out[3]) / np.maximum(np.abs(out[3]), 1e-3)) < 1e-3
 
 
+@pytest.mark.parametrize("shape,splitk", [((1024, 1024, 1024), -1), ((1024, 1024, 1024), 2), ((300, 2048, 272), 8), ((129, 4104, 132), 3),
+                                          ((513, 1032, 520), -1), ((1536, 1536, 1536), -1), ((640, 520, 384), 2)],
+                         ids=lambda v: "x".join(map(str, v)) if isinstance(v, tuple) else f"splitk{v}")
+def test_f32_split_k_for_small_problems_is_deterministic_and_accurate(shape, splitk):
+    """problems that cannot fill the chip with whole 128 x 128 tiles are cut along K into up to 8
+    chunks; the copies of the tile grid run side by side and a second kernel adds the partial planes in ascending
+    order.  Same bits on every launch, inside 1e-5 of fp64 like every fp32 fast path, K chunks that end mid-slab
+    (4104 / 3, 520 / 2) included; the kernel name says what ran."""
+    n, k, m = shape
+    rng = np.random.default_rng(k + n)
+    a = rng.uniform(-3, 10, size=(n, k)).astype(np.float32)
+    b = rng.uniform(-3, 10, size=(k, m)).astype(np.float32)
+    exact = a.astype(np.float64) @ b.astype(np.float64)
+    scale = np.abs(a.astype(np.float64)) @ np.abs(b.astype(np.float64))
+    try:
+        g.set_tuning("f32_splitk", splitk)
+        if splitk > 1:
+            g.set_tuning("f32_variant", 35)
+        name = g.kernel_name(g.make_config("float"), n, k, m)
+        c1, _ = g.matmul_capi(a, b)
+        c2, _ = g.matmul_capi(a, b)
+        g.set_tuning("f32_splitk", 1)
+        c_one, _ = g.matmul_capi(a, b)
+    finally:
+        g.set_tuning("f32_splitk", -1)
+        g.set_tuning("f32_variant", -1)
+    assert "splitk" in name, name                      # every case here is small enough to split
+    assert np.array_equal(c1, c2)
+    assert np.max(np.abs(c1 - exact) / scale) < 2e-6
+    assert np.max(np.abs(c1 - c_one) / scale) < 5e-6   # close to the unsplit kernel, not the same summation order
+
+
 @pytest.mark.parametrize("shape", [(516, 528, 528), (4, 16, 16), (300, 64, 272), (1024, 4112, 512), (260, 8, 4)],
                          ids=lambda s: "x".join(map(str, s)))
 def test_f32_mfma_transposed_a_layout(shape):
@@ -100,8 +132,11 @@ def test_f32_mfma_transposed_a_layout(shape):
     exact = a.astype(np.float64) @ b.astype(np.float64)
     rel = np.abs(c - exact) / exact
     assert rel.max() < F32_TOL, (np.unravel_index(np.argmax(rel), rel.shape), rel.max())
-    # and it is the same arithmetic as the row-major path: identical bits
+    # and it is the same arithmetic as the row-major path: identical bits (split-K of small problems off: the K x N layout
+    # never splits, and a split changes the summation order)
+    g.set_tuning("f32_splitk", 1)
     c_rm, _ = g.matmul_capi(a, b)
+    g.set_tuning("f32_splitk", -1)
     assert np.array_equal(c, c_rm)
 
 

@@ -946,6 +946,8 @@ static bool sdma_fits(const Problem &p, unsigned bk) {
   return p.k >= bk && span < (1ull << 32) && spanb < (1ull << 32);
 }
 
+int mfma_f32_splitk(const Problem &, int) { return 1; }   // the lab edition never splits K
+
 int mfma_f32_resolve(const Problem &p, int variant) {
   if (!mfma_f32_serves(p)) return -1;
   if (p.a_transposed) return 8;

@@ -478,12 +478,6 @@ size_t mfma_f32_split_workspace_bytes(const Problem &p) {
   return ((size_t)((p.n + 255) / 256) + (size_t)((p.m + 255) / 256)) * slabs * Packed::SLAB_BYTES;
 }
 
-int mfma_f32_split_release(int dev) {   // the lab edition still caches its workspace in the device's default pool
-  hipMemPool_t pool;
-  hipError_t e = hipDeviceGetDefaultMemPool(&pool, dev);
-  return e != hipSuccess ? (int)e : (int)hipMemPoolTrimTo(pool, 0);
-}
-
 // variant (split_variant knob): -1 / 0 = default (6 products, ping-pong schedule, flush every 8256 k); otherwise a bit
 // mask: 1 first schedule of the round (one barrier per stage, fragment reads ahead of each MFMA group, s_setprio around
 // the group), 2 three products (planes 1 and 2 only), 4 no flush, 8 plain hipMalloc/hipFree workspace (diagnosis),
