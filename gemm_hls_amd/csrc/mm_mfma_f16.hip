@@ -304,10 +304,10 @@ __global__ __launch_bounds__(G::THREADS) void mfma_f16_kernel(const _Float16 *__
 // every reader passed with lgkmcnt(0) (replayed on the CPU by tests/test_schedules.py).
 //
 // pingpong_k32: 32-deep slabs for A and B (K % 32 == 0, the reference's own contract for half: 64-byte bus = 32
-// elements, host/RunHardware.cpp:50-55), on the 32x32x16 instruction; row-major A or K x N A (staged and gathered like B).
-//   A slab image [256 rows][32 k]: 64-B rows, 16-B chunk index XORed with (row>>2)&3 (a
-//   ds_read_b128 lane group = 16 rows x 16 B must cover all 16 slots of the 256-B bank row);
-//   B slab image [32 k][256 cols]: chunk index ^ (k&3)<<2.
+// elements, host/RunHardware.cpp:50-55), on the 16x16x32 instruction since round 3 (one slab = one MFMA k; the 32x32x16
+// edition is in the lab); row-major A or K x N A (staged and gathered like B).
+//   A slab image [256 rows][32 k]: 64-B rows, 16-B chunk index XORed with (-(row>>2))&3;
+//   B slab image [32 k][256 cols]: chunk index ^ (k&3)<<2 ^ ((k>>3)&1)<<1.
 struct GeoPP {
   static constexpr int BM = 256, BN = 256, BK = 32, NS = 4, THREADS = 512;
   static constexpr int TM = 4, TN = 2;  // 128 x 64 per wave
@@ -326,14 +326,14 @@ __global__ __launch_bounds__(GeoPP::THREADS) void mfma_f16_pp_kernel(const _Floa
                                                                        unsigned M, unsigned tiles_n, unsigned tiles_m,
                                                                        unsigned kBand) {
   using G = GeoPP;
-  constexpr int TM = G::TM, TN = G::TN;
+  constexpr int RB = 8, NB = 4;  // 16-row / 16-column blocks of a wavefront's 128 x 64 part (16x16x32 instruction, round 3)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const unsigned lane = threadIdx.x & 63u;
   const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const unsigned group = wave >> 2;                 // waves w and w+4 share a SIMD
   const unsigned wq = wave & 3u;
   const unsigned wm = wq >> 1, wn = (wq & 1u) * 2 + group;  // 2 x 4 wave grid; partners sit side by side
-  const unsigned lo = lane & 31u, hi = lane >> 5;
+  const unsigned l15 = lane & 15u, g = lane >> 4;
 
   const unsigned nwg = tiles_n * tiles_m;
   const unsigned lin = xcd_remap(blockIdx.x, nwg);
@@ -342,14 +342,17 @@ __global__ __launch_bounds__(GeoPP::THREADS) void mfma_f16_pp_kernel(const _Floa
   const unsigned row0 = (band * kBand + within % rows_in_band) * G::BM, col0 = (within / rows_in_band) * G::BN;
 
   // ---- DMA: per-lane offsets (constant) and uniform bases (advance with k) ----------------------
+  //   row-major A: 16 pieces of 16 rows x 64 B, source chunk = pc ^ (-(row>>2))&3 (the swizzle under which the
+  //     16x16 operand read -- row l&15, chunk l>>4 -- covers 16 distinct slots per ds_read_b128 service group);
+  //   B, and a K x N A: 16 pieces of 2 k-rows x 512 B, source chunk = pb ^ (k&3)<<2 ^ ((k>>3)&1)<<1 (see pingpong_16x16x32)
   unsigned voff_a[2], voff_b[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const unsigned piece = wave + 8 * i;               // 16 A pieces of 16 rows x 64 B
+    const unsigned piece = wave + 8 * i;
     const unsigned row = piece * 16 + lane / 4, pc = lane % 4;
-    const unsigned chunk = pc ^ ((row >> 2) & 3u);
-    const unsigned kr = piece * 2 + lane / 32, pb = lane % 32;  // 16 B pieces of 2 k-rows x 512 B
-    const unsigned lc = pb ^ ((kr & 3u) << 2);
+    const unsigned chunk = pc ^ ((0u - (row >> 2)) & 3u);
+    const unsigned kr = piece * 2 + lane / 32, pb = lane % 32;
+    const unsigned lc = pb ^ ((kr & 3u) << 2) ^ (((kr >> 3) & 1u) << 1);
     voff_a[i] = AT ? kr * N * 2 + (min(row0 + lc * 8, N - 8) - row0) * 2  // K x N: 2 k-rows x 256 tile rows, like B
                    : (min(row0 + row, N - 1) - row0) * K * 2 + chunk * 16;
     voff_b[i] = kr * M * 2 + (min(col0 + lc * 8, M - 8) - col0) * 2;
@@ -374,74 +377,58 @@ __global__ __launch_bounds__(GeoPP::THREADS) void mfma_f16_pp_kernel(const _Floa
   };
 
   // ---- fragment addresses (per lane, constant) ---------------------------------------------------
-  // A: row = wm*128 + mi*32 + lo ; chunk(ks) = (2*ks + hi) ^ ((lo>>2)&3) = (2*ks) ^ c, c = hi ^ ((lo>>2)&3)
-  const unsigned ca = hi ^ ((lo >> 2) & 3u);
-  const unsigned a_row_byte = (wm * 128 + lo) * (G::BK * 2);
-  const unsigned a_off[2] = {a_row_byte + ca * 16, a_row_byte + (ca ^ 2u) * 16};
-  // B (transpose read): x = lane&15 -> k row r = x>>2 of a 4-row block, 8-B piece (x&3) of the block's 32 B
-  //   k = ks*16 + 8*hi + 4*h + r ; logical chunk = wn*8 + ni*4 + 2*gq + ((x&3)>>1) ; physical = logical ^ (r<<2)
-  const unsigned x = lane & 15u, gq = (lane >> 4) & 1u, r = x >> 2;
-  unsigned b_off[TN];
+  // A (row-major): row = wm*128 + rb*16 + l15, chunk g, physical = g ^ (-(l15>>2))&3
+  const unsigned a_off = (wm * 128 + l15) * (G::BK * 2) + (g ^ ((0u - (l15 >> 2)) & 3u)) * 16;
+  // B (transpose read): k = 8*g + 4*h2 + r, r = l15>>2; 8-byte piece l15&3 of the block's 32 B (16 columns)
+  const unsigned r = l15 >> 2, piece = l15 & 3u, xk = (r << 2) ^ ((g & 1u) << 1);
+  unsigned b_off[NB];
 #pragma unroll
-  for (int ni = 0; ni < TN; ++ni) {
-    const unsigned logical = wn * 8 + ni * 4 + 2 * gq + ((x & 3u) >> 1);
-    b_off[ni] = G::A_BYTES + (8 * hi + r) * G::BROW + (logical ^ (r << 2)) * 16 + (x & 1u) * 8;
-  }
-  unsigned at_off[TM];  // K x N layout of A: the same gather over the [k][256 rows] image (this wave's rows wm*128 ..)
+  for (int nb = 0; nb < NB; ++nb)
+    b_off[nb] = G::A_BYTES + (8 * g + r) * G::BROW + ((wn * 8 + nb * 2 + (piece >> 1)) ^ xk) * 16 + (piece & 1u) * 8;
+  // K x N A: the same gather over the [k][256 rows] image; a wavefront's 128 rows are chunks wm*16 .. +15, block rb = 2 chunks
+  unsigned at_off[RB];
 #pragma unroll
-  for (int mi = 0; mi < TM; ++mi) {
-    const unsigned logical = wm * 16 + mi * 4 + 2 * gq + ((x & 3u) >> 1);
-    at_off[mi] = (8 * hi + r) * (G::BM * 2) + (logical ^ (r << 2)) * 16 + (x & 1u) * 8;
-  }
+  for (int rb = 0; rb < RB; ++rb)
+    at_off[rb] = (8 * g + r) * (G::BM * 2) + ((wm * 16 + rb * 2 + (piece >> 1)) ^ xk) * 16 + (piece & 1u) * 8;
 
-  f32x16 acc[TM][TN];
+  using f32x4 = __attribute__((ext_vector_type(4))) float;
+  f32x4 acc[RB][NB];
 #pragma unroll
-  for (int mi = 0; mi < TM; ++mi)
+  for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-    for (int ni = 0; ni < TN; ++ni) acc[mi][ni] = (f32x16)0.0f;
+    for (int nb = 0; nb < NB; ++nb) acc[rb][nb] = (f32x4)0.0f;
 
   auto sync = [&]() {
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
   };
-  // one slab: load segment | barrier | compute segment | barrier
+  auto tr2 = [&](const char *p, unsigned row_bytes) {
+    const s4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s4 __attribute__((address_space(3))) *)(lptr_t)p);
+    const s4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s4 __attribute__((address_space(3))) *)(lptr_t)(p + 4 * row_bytes));
+    return join(v0, v1);
+  };
+  // one slab (= one MFMA k): load segment | barrier | compute segment | barrier
   auto phase = [&](auto bufc, unsigned u) {
     constexpr int BUF = decltype(bufc)::value;
     const char *base = smem + BUF * G::STAGE_BYTES;
-    h8 af[TM][2], bf[TN][2];
+    h8 af[RB], bf[NB];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int nb = 0; nb < NB; ++nb) bf[nb] = tr2(base + b_off[nb], G::BROW);
 #pragma unroll
-      for (int ni = 0; ni < TN; ++ni) {
-        const char *p = base + b_off[ni] + ks * 16 * G::BROW;
-        const s4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s4 __attribute__((address_space(3))) *)(lptr_t)p);
-        const s4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s4 __attribute__((address_space(3))) *)(lptr_t)(p + 4 * G::BROW));
-        bf[ni][ks] = join(v0, v1);
-      }
-#pragma unroll
-      for (int mi = 0; mi < TM; ++mi) {
-        if (AT) {
-          const char *p = base + at_off[mi] + ks * 16 * (G::BM * 2);
-          const s4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s4 __attribute__((address_space(3))) *)(lptr_t)p);
-          const s4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s4 __attribute__((address_space(3))) *)(lptr_t)(p + 4 * G::BM * 2));
-          af[mi][ks] = join(v0, v1);
-        } else {
-          af[mi][ks] = *(const h8 *)(base + a_off[ks] + mi * 32 * (G::BK * 2));
-        }
-      }
+    for (int rb = 0; rb < RB; ++rb) {
+      if (AT) af[rb] = tr2(base + at_off[rb], G::BM * 2);
+      else af[rb] = *(const h8 *)(base + a_off + rb * 16 * (G::BK * 2));
     }
     issue(u + 3, (BUF + 3) & 3);
     asm volatile("s_waitcnt vmcnt(8)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");  // own pieces of slab u+1 landed; fragments in registers
     sync();
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
+    for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-      for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < TN; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mi][ks], bf[ni][ks], acc[mi][ni], 0, 0, 0);
+      for (int nb = 0; nb < NB; ++nb)
+        acc[rb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[rb], bf[nb], acc[rb][nb], 0, 0, 0);
     __builtin_amdgcn_s_setprio(0);
     sync();
   };
@@ -465,17 +452,16 @@ __global__ __launch_bounds__(GeoPP::THREADS) void mfma_f16_pp_kernel(const _Floa
   sync();
 
   // ---- epilogue: one rounding f32 -> binary16, staged through this wave's 16 KiB slice of the ring
+  //      (C/D of the 16x16 form: column l15, rows 4*g + i)
   {
     char *slice = smem + wave * (128 * 128);
 #pragma unroll
-    for (int mi = 0; mi < TM; ++mi)
+    for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-      for (int ni = 0; ni < TN; ++ni)
+      for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-        for (int rr = 0; rr < 16; ++rr) {
-          const unsigned row = mi * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * hi;
-          *(_Float16 *)(slice + row * 128 + (ni * 32 + lo) * 2) = (_Float16)acc[mi][ni][rr];
-        }
+        for (int i = 0; i < 4; ++i)
+          *(_Float16 *)(slice + (rb * 16 + 4 * g + i) * 128 + (nb * 16 + l15) * 2) = (_Float16)acc[rb][nb][i];
     using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 #pragma unroll
     for (int it = 0; it < 128 * 8 / 64; ++it) {

@@ -271,29 +271,32 @@ __global__ __launch_bounds__(GeoI8PP::THREADS) void mfma_i8_pp_kernel(const sign
                                                                         signed char *__restrict__ C, unsigned N, unsigned K,
                                                                         unsigned M, unsigned tiles_n, unsigned tiles_m,
                                                                         unsigned kBand) {
+  // pingpong_k64 on v_mfma_i32_16x16x64_i8 since round 3 (one 64-deep slab = one MFMA k; the 32x32x32 edition is in the lab)
   using G = GeoI8PP;
-  constexpr int TM = G::TM, TN = G::TN;
+  constexpr int RB = 8, NB = 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const unsigned lane = threadIdx.x & 63u;
   const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const unsigned group = wave >> 2, wq = wave & 3u;
   const unsigned wm = wq >> 1, wn = (wq & 1u) * 2 + group;
-  const unsigned lo = lane & 31u, hi = lane >> 5;
+  const unsigned l15 = lane & 15u, g = lane >> 4;
 
   const unsigned lin = xcd_remap(blockIdx.x, tiles_n * tiles_m);
   const unsigned band = lin / (kBand * tiles_m), within = lin % (kBand * tiles_m);
   const unsigned rows_in_band = min(kBand, tiles_n - band * kBand);
   const unsigned row0 = (band * kBand + within % rows_in_band) * G::BM, col0 = (within / rows_in_band) * G::BN;
 
+  // DMA.  Row-major A: 16 pieces of 16 rows x 64 B, source chunk = pc ^ (-(row>>2))&3; B and a K x N A: 16 pieces of
+  // 4 k-rows x 256 B, source chunk = pb ^ (((k&7)<<1) | ((k>>4)&1))  (see pingpong_16x16x64)
   unsigned voff_a[2], voff_b[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const unsigned piece = wave + 8 * i;
-    const unsigned row = piece * 16 + lane / 4, pc = lane % 4;         // 16 A pieces of 16 rows x 64 B
-    const unsigned kr = piece * 4 + lane / 16, pb = lane % 16;         // 16 B pieces of 4 k-rows x 256 B
-    const unsigned lc = pb ^ ((kr & 7u) << 1);
+    const unsigned row = piece * 16 + lane / 4, pc = lane % 4;
+    const unsigned kr = piece * 4 + lane / 16, pb = lane % 16;
+    const unsigned lc = pb ^ (((kr & 7u) << 1) | ((kr >> 4) & 1u));
     voff_a[i] = AT ? kr * N + (min(row0 + lc * 16, N - 16) - row0)
-                   : (min(row0 + row, N - 1) - row0) * K + (pc ^ ((row >> 2) & 3u)) * 16;
+                   : (min(row0 + row, N - 1) - row0) * K + (pc ^ ((0u - (row >> 2)) & 3u)) * 16;
     voff_b[i] = kr * M + (min(col0 + lc * 16, M - 16) - col0);
   }
   const char *a_base = (const char *)A + (AT ? (size_t)row0 : (size_t)row0 * K);
@@ -315,69 +318,53 @@ __global__ __launch_bounds__(GeoI8PP::THREADS) void mfma_i8_pp_kernel(const sign
                  : "memory");
   };
 
-  // A fragment: row = wm*128 + mi*32 + lo, chunk (2*ks + hi) ^ ((lo>>2)&3)
-  const unsigned ca = hi ^ ((lo >> 2) & 3u);
-  const unsigned a_row_byte = (wm * 128 + lo) * G::BK;
-  const unsigned a_off[2] = {a_row_byte + ca * 16, a_row_byte + (ca ^ 2u) * 16};
-  // B fragment (8-bit transpose read): y = lane&15 -> block row r = y>>1, 8-byte half q = y&1; gq = 16-col half
-  //   k = ks*32 + 16*hi + 8*h + r ; 32-col block = wn*2 + ni, physical block = logical ^ r
-  const unsigned y = lane & 15u, gq = (lane >> 4) & 1u, r = y >> 1, q = y & 1u;
-  unsigned b_off[TN];
+  // A (row-major): row = wm*128 + rb*16 + l15, chunk g (16 k bytes), physical = g ^ (-(l15>>2))&3
+  const unsigned a_off = (wm * 128 + l15) * G::BK + (g ^ ((0u - (l15 >> 2)) & 3u)) * 16;
+  // B (8-bit transpose read): block row r = l15>>1 (k = 16*g + 8*h2 + r), 8-byte half q = l15&1 of the 16 columns
+  const unsigned r = l15 >> 1, q = l15 & 1u, xk = (r << 1) | (g & 1u);
+  unsigned b_off[NB];
 #pragma unroll
-  for (int ni = 0; ni < TN; ++ni)
-    b_off[ni] = G::A_BYTES + (16 * hi + r) * G::BROW + 8 * q + ((((wn * 2 + ni) ^ r) * 2) + gq) * 16;
-  unsigned at_off[TM];  // K x N A: the same gather over the [k][256 rows] image
+  for (int nb = 0; nb < NB; ++nb) b_off[nb] = G::A_BYTES + (16 * g + r) * G::BROW + 8 * q + ((wn * 4 + nb) ^ xk) * 16;
+  unsigned at_off[RB];  // K x N A: the same gather over the [k][256 rows] image (this wavefront's 16-row chunks wm*8 .. +7)
 #pragma unroll
-  for (int mi = 0; mi < TM; ++mi)
-    at_off[mi] = (16 * hi + r) * G::BM + 8 * q + ((((wm * 4 + mi) ^ r) * 2) + gq) * 16;
+  for (int rb = 0; rb < RB; ++rb) at_off[rb] = (16 * g + r) * G::BM + 8 * q + ((wm * 8 + rb) ^ xk) * 16;
 
-  i32x16 acc[TM][TN];
+  i32x4 acc[RB][NB];
 #pragma unroll
-  for (int mi = 0; mi < TM; ++mi)
+  for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-    for (int ni = 0; ni < TN; ++ni) acc[mi][ni] = (i32x16)0;
+    for (int nb = 0; nb < NB; ++nb) acc[rb][nb] = (i32x4)0;
 
   auto sync = [&]() {
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
   };
+  auto tr2 = [&](const char *p, unsigned row_bytes) {
+    const v2i v0 = __builtin_amdgcn_ds_read_tr8_b64_v2i32((v2i __attribute__((address_space(3))) *)(lptr_t)p);
+    const v2i v1 = __builtin_amdgcn_ds_read_tr8_b64_v2i32((v2i __attribute__((address_space(3))) *)(lptr_t)(p + 8 * row_bytes));
+    return join(v0, v1);
+  };
   auto phase = [&](auto bufc, unsigned u) {
     constexpr int BUF = decltype(bufc)::value;
     const char *base = smem + BUF * G::STAGE_BYTES;
-    i32x4 af[TM][2], bf[TN][2];
+    i32x4 af[RB], bf[NB];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int nb = 0; nb < NB; ++nb) bf[nb] = tr2(base + b_off[nb], G::BROW);
 #pragma unroll
-      for (int ni = 0; ni < TN; ++ni) {
-        const char *p = base + b_off[ni] + ks * 32 * G::BROW;
-        const v2i v0 = __builtin_amdgcn_ds_read_tr8_b64_v2i32((v2i __attribute__((address_space(3))) *)(lptr_t)p);
-        const v2i v1 = __builtin_amdgcn_ds_read_tr8_b64_v2i32((v2i __attribute__((address_space(3))) *)(lptr_t)(p + 8 * G::BROW));
-        bf[ni][ks] = join(v0, v1);
-      }
-#pragma unroll
-      for (int mi = 0; mi < TM; ++mi) {
-        if (AT) {
-          const char *p = base + at_off[mi] + ks * 32 * G::BM;
-          const v2i v0 = __builtin_amdgcn_ds_read_tr8_b64_v2i32((v2i __attribute__((address_space(3))) *)(lptr_t)p);
-          const v2i v1 = __builtin_amdgcn_ds_read_tr8_b64_v2i32((v2i __attribute__((address_space(3))) *)(lptr_t)(p + 8 * G::BM));
-          af[mi][ks] = join(v0, v1);
-        } else {
-          af[mi][ks] = *(const i32x4 *)(base + a_off[ks] + mi * 32 * G::BK);
-        }
-      }
+    for (int rb = 0; rb < RB; ++rb) {
+      if (AT) af[rb] = tr2(base + at_off[rb], G::BM);
+      else af[rb] = *(const i32x4 *)(base + a_off + rb * 16 * G::BK);
     }
     issue(u + 3, (BUF + 3) & 3);
     asm volatile("s_waitcnt vmcnt(8)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
     sync();
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
+    for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-      for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < TN; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[mi][ks], bf[ni][ks], acc[mi][ni], 0, 0, 0);
+      for (int nb = 0; nb < NB; ++nb)
+        acc[rb][nb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[rb], bf[nb], acc[rb][nb], 0, 0, 0);
     __builtin_amdgcn_s_setprio(0);
     sync();
   };
@@ -399,18 +386,15 @@ __global__ __launch_bounds__(GeoI8PP::THREADS) void mfma_i8_pp_kernel(const sign
   if (!shifted) sync();
   sync();
 
-  // epilogue: low 8 bits of the i32 sums through this wave's 8 KiB slice, 16-B global stores
+  // epilogue: low 8 bits of the i32 sums through this wave's 8 KiB slice, 16-B global stores (C/D: column l15, rows 4*g + i)
   {
     char *slice = smem + wave * (128 * 64);
 #pragma unroll
-    for (int mi = 0; mi < TM; ++mi)
+    for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-      for (int ni = 0; ni < TN; ++ni)
+      for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-        for (int rr = 0; rr < 16; ++rr) {
-          const unsigned row = mi * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * hi;
-          slice[row * 64 + ni * 32 + lo] = (char)acc[mi][ni][rr];
-        }
+        for (int i = 0; i < 4; ++i) slice[(rb * 16 + 4 * g + i) * 64 + nb * 16 + l15] = (char)acc[rb][nb][i];
     using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 #pragma unroll
     for (int it = 0; it < 128 * 4 / 64; ++it) {

@@ -390,3 +390,66 @@ def test_pingpong_16x16x64_i8_b_image_roundtrip_and_banks():
                 assert k == 16 * (l >> 4) + 8 * h2 + j and col == wn * 64 + nb * 16 + (l & 15)
         b64_half_banks_disjoint(addr, range(0, 32))
         b64_half_banks_disjoint(addr, range(32, 64))
+
+
+def test_pingpong_16x16_a_operand_on_64_byte_rows_roundtrip_and_banks():
+    """pingpong_k32 / pingpong_k64 (round 3): A slab [256 rows][64 B], DMA piece = 16 rows, source chunk =
+    pc ^ (-(row>>2))&3; the 16x16 operand read takes row l&15 and chunk l>>4.  (The (row>>2)&3 swizzle of the 32x32
+    kernels would put rows 0-3 / chunk 0 and rows 4-7 / chunk 1 of one service group into the same slots.)"""
+    lds = {}
+    for piece in range(16):
+        for lane in range(64):
+            row, pc = piece * 16 + lane // 4, lane % 4
+            lds[piece * 1024 + lane * 16] = (row, pc ^ ((0 - (row >> 2)) & 3))
+    for wm, rb in itertools.product(range(2), range(8)):
+        def addr(l):
+            l15, g = l & 15, l >> 4
+            return (wm * 128 + l15) * 64 + (g ^ ((0 - (l15 >> 2)) & 3)) * 16 + rb * 16 * 64
+        for l in range(64):
+            row, lc = lds[addr(l)]
+            assert row == wm * 128 + rb * 16 + (l & 15) and lc == (l >> 4)
+        assert_conflict_free_b128(addr)
+
+
+def test_pingpong_16x16_kxn_a_gather_f16_and_i8():
+    """K x N A on the 16x16 ping-pong kernels: the A slab is staged [k][256 rows] with B's swizzle and the operand
+    (row l&15 of block rb, k = 8g.. / 16g..) is gathered by the same pair of transpose reads as B's."""
+    # f16: [32 k][256 rows] halves
+    lds = {}
+    for piece in range(16):
+        for lane in range(64):
+            kr, pb = piece * 2 + lane // 32, lane % 32
+            lds[piece * 1024 + lane * 16] = (kr, pb ^ ((kr & 3) << 2) ^ (((kr >> 3) & 1) << 1))
+    for h2, rb, wm in itertools.product(range(2), range(8), range(2)):
+        def addr(l):
+            l15, g = l & 15, l >> 4
+            r, piece = l15 >> 2, l15 & 3
+            xk = (r << 2) ^ ((g & 1) << 1)
+            return (8 * g + r) * 512 + ((wm * 16 + rb * 2 + (piece >> 1)) ^ xk) * 16 + (piece & 1) * 8 + h2 * 4 * 512
+        for l in range(64):
+            i, grp = l & 15, l & ~15
+            for j in range(4):
+                a = addr(grp + 4 * j + (i >> 2)) + 2 * (i & 3)
+                kr, lc = lds[(a // 16) * 16]
+                assert kr == 8 * (l >> 4) + 4 * h2 + j and lc * 8 + (a % 16) // 2 == wm * 128 + rb * 16 + (l & 15)
+        b64_half_banks_disjoint(addr, range(0, 32))
+        b64_half_banks_disjoint(addr, range(32, 64))
+    # i8: [64 k][256 rows] bytes
+    lds = {}
+    for piece in range(16):
+        for lane in range(64):
+            kr, pb = piece * 4 + lane // 16, lane % 16
+            lds[piece * 1024 + lane * 16] = (kr, pb ^ (((kr & 7) << 1) | ((kr >> 4) & 1)))
+    for h2, rb, wm in itertools.product(range(2), range(8), range(2)):
+        def addr(l):
+            l15, g = l & 15, l >> 4
+            r, q = l15 >> 1, l15 & 1
+            return (16 * g + r) * 256 + 8 * q + ((wm * 8 + rb) ^ ((r << 1) | (g & 1))) * 16 + h2 * 8 * 256
+        for l in range(64):
+            i, grp = l & 15, l & ~15
+            for j in range(8):
+                a = addr(grp + 2 * j + (i >> 3)) + (i & 7)
+                kr, lc = lds[(a // 16) * 16]
+                assert kr == 16 * (l >> 4) + 8 * h2 + j and lc * 16 + a % 16 == wm * 128 + rb * 16 + (l & 15)
+        b64_half_banks_disjoint(addr, range(0, 32))
+        b64_half_banks_disjoint(addr, range(32, 64))

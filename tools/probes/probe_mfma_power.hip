@@ -184,13 +184,60 @@ __global__ __launch_bounds__(512) void k2(float *out, unsigned long long *cyc, i
   if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 8 + (threadIdx.x >> 6)] = t1 - t0;
 }
 
+// fp32 / fp64 matrix instructions, the same question: v_mfma_f32_32x32x2_f32 (64 cycles) vs v_mfma_f32_16x16x4_f32 (32 cycles),
+// random operands, 64 x 128 wavefront tile (2 x 4 accumulators of 16 registers, or 4 x 8 of 4).
+//   KIND 0: f32 32x32x2, 2x4 block   1: f32 16x16x4, 4x8 block
+template <int KIND>
+__global__ __launch_bounds__(512) void k3(float *out, unsigned long long *cyc, int iters) {
+  unsigned st = threadIdx.x * 2654435761u + blockIdx.x * 40503u + 12345u;
+  constexpr bool BIG = KIND == 0;
+  constexpr int TA = BIG ? 2 : 4, TB = BIG ? 4 : 8, KS = 4;   // KS k-steps' worth of distinct operand registers
+  using acc_t = typename std::conditional<BIG, f32x16, f32x4>::type;
+  float a[KS][TA], b[KS][TB];
+  acc_t acc[TA][TB];
+#pragma unroll
+  for (int q = 0; q < KS; ++q) {
+#pragma unroll
+    for (int i = 0; i < TA; ++i) { st = st * 1664525u + 1013904223u; a[q][i] = 1.0f + 9.0f * (st >> 8) * (1.0f / 16777216.0f); }
+#pragma unroll
+    for (int i = 0; i < TB; ++i) { st = st * 1664525u + 1013904223u; b[q][i] = 1.0f + 9.0f * (st >> 8) * (1.0f / 16777216.0f); }
+  }
+#pragma unroll
+  for (int i = 0; i < TA; ++i)
+#pragma unroll
+    for (int j = 0; j < TB; ++j) acc[i][j] = (acc_t)0.0f;
+  __syncthreads();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int q = 0; q < KS; ++q)
+#pragma unroll
+      for (int i = 0; i < TA; ++i)
+#pragma unroll
+        for (int j = 0; j < TB; ++j) {
+          if constexpr (BIG) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][i], b[q][j], acc[i][j], 0, 0, 0);
+          else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q][i], b[q][j], acc[i][j], 0, 0, 0);
+        }
+  }
+  float s = 0;
+#pragma unroll
+  for (int i = 0; i < TA; ++i)
+#pragma unroll
+    for (int j = 0; j < TB; ++j) s += acc[i][j][0];
+  asm volatile("s_nop 0" ::"v"(s) : "memory");
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  out[blockIdx.x * 512 + threadIdx.x] = s;
+  if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 8 + (threadIdx.x >> 6)] = t1 - t0;
+}
+
 template <int MODE>
 int run(const char *name, int mfma_per_iter, double flop_per_mfma, float *d, unsigned long long *dc) {
   const int blocks = 256, iters = 1 << 17;
   hipEvent_t e0, e1;
   CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
   auto launch = [&]() {
-    if constexpr (MODE >= 10) k2<MODE - 10><<<blocks, 512>>>(d, dc, iters);
+    if constexpr (MODE >= 20) k3<MODE - 20><<<blocks, 512>>>(d, dc, iters / 8);
+    else if constexpr (MODE >= 10) k2<MODE - 10><<<blocks, 512>>>(d, dc, iters);
     else k<MODE><<<blocks, 512>>>(d, dc, iters);
   };
   launch();   // warm-up: lets the power management settle on this load
@@ -204,7 +251,7 @@ int run(const char *name, int mfma_per_iter, double flop_per_mfma, float *d, uns
   CHECK(hipMemcpy(c.data(), dc, c.size() * 8, hipMemcpyDeviceToHost));
   unsigned long long mx = 0;
   for (auto v : c) mx = std::max(mx, v);
-  const double inst = (double)iters * mfma_per_iter;                     // per wave
+  const double inst = (double)(MODE >= 20 ? iters / 8 : iters) * mfma_per_iter;   // per wave
   const double tops = 256.0 * 8 * inst * flop_per_mfma / (ms * 1e-3) / 1e12;
   printf("%-58s %7.1f TF  clock >= %5.3f GHz  %6.2f cyc/MFMA/SIMD  %7.2f ms\n", name, tops, (double)mx / (ms * 1e6),
          (double)mx / (inst * 2), ms);
@@ -225,6 +272,8 @@ int main() {
     run<11>("i8 16x16x64, 8x4 block", 64, 32768, d, dc);
     run<12>("bf16 32x32x16, 4x2 block", 16, 32768, d, dc);
     run<13>("bf16 16x16x32, 8x4 block", 64, 16384, d, dc);
+    run<20>("f32 32x32x2, 2x4 block", 32, 4096, d, dc);
+    run<21>("f32 16x16x4, 4x8 block", 128, 2048, d, dc);
   }
   return 0;
 }
