@@ -558,6 +558,7 @@ const char *mm_kernel_name(const mm_config_t *cfg, unsigned n, unsigned k, unsig
                                                 "mfma_f32_128x128x32_w4x2_splitk6", "mfma_f32_128x128x32_w4x2_splitk7",
                                                 "mfma_f32_128x128x32_w4x2_splitk8"};
       const int splits = mm::mfma_f32_splitk(p, v);
+      if (splits == 0) return "mfma_f32_128x128x32_w4x2_streamk";
       return splits > 1 ? split_names[splits] : mm::mfma_f32_name(v);
     }
     case FAM_MFMA_F64: return mm::mfma_f64_name(p);

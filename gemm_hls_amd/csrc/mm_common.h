@@ -171,7 +171,7 @@ inline unsigned band_rows(unsigned bm = 256, unsigned bn = 256, unsigned per_cu 
 // problems and leaves CUs idle on small ones.  Estimated time of a candidate ~ (workgroups the
 // busiest CU runs) x tile area / relative efficiency; the smallest wins.
 struct TileCandidate { int id; unsigned bm, bn, per_cu; double eff; };
-inline int pick_tile(const TileCandidate *cands, int count, unsigned n, unsigned m) {
+inline int pick_tile(const TileCandidate *cands, int count, unsigned n, unsigned m, double *best_time = nullptr) {
   double best = 0;
   int pick = cands[0].id;
   for (int i = 0; i < count; ++i) {
@@ -181,6 +181,7 @@ inline int pick_tile(const TileCandidate *cands, int count, unsigned n, unsigned
     const double t = ((double)full * c.per_cu + (double)((rem + 255) / 256)) * c.bm * c.bn / c.eff;
     if (best == 0 || t < best * 0.999) { best = t; pick = c.id; }
   }
+  if (best_time) *best_time = best;
   return pick;
 }
 

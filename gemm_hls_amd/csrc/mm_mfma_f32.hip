@@ -108,13 +108,13 @@ struct Geo {
   static_assert(DMA_ == Dma::VectorAddress || READS_ == Reads::Pipelined, "the scalar-base DMA pieces are placed by hand");
 };
 
+// One k-range of one output tile: A / B point at the first k of the range (row stride of A: lda), K = its length, the
+// result goes to Cst[row * ldc + col] for rows < Nst, cols < Mst.  For a whole tile of C that is (C, M, N, M); a partial
+// tile of a stream-K launch targets a 128 x 128 scratch slot instead (ldc = 128, no limits).
 template <typename G, bool AT>
-__global__ __launch_bounds__(G::THREADS, G::MIN_WAVES) void mfma_f32_kernel(const float *__restrict__ A,
-                                                              const float *__restrict__ B,
-                                                              float *__restrict__ C, unsigned N,
-                                                              unsigned K, unsigned M,
-                                                              unsigned tiles_n, unsigned tiles_m,
-                                                              unsigned kBand, unsigned kChunk, float *__restrict__ partials) {
+__device__ __forceinline__ void tile_body(const float *__restrict__ A, const float *__restrict__ B, float *__restrict__ Cst,
+                                          unsigned N, unsigned K, unsigned M, unsigned lda, unsigned ldc, unsigned Nst,
+                                          unsigned Mst, unsigned row0, unsigned col0) {
   constexpr int TM = G::TM, TN = G::TN, BK = G::BK, NS = G::NS, CPR = G::CPR;
   constexpr bool TWO_LEVEL = G::CHAIN == Chain::TwoLevel, FLUSH = G::CHAIN == Chain::FlushIntoC;
   constexpr bool PIPELINED = G::READS == Reads::Pipelined, SDMA = G::DMA == Dma::ScalarBase;
@@ -124,29 +124,6 @@ __global__ __launch_bounds__(G::THREADS, G::MIN_WAVES) void mfma_f32_kernel(cons
   const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const unsigned wm = wave / G::WN, wn = wave % G::WN;
   const unsigned lo = lane & 31u, hi = lane >> 5;
-
-  // ---- split-K launches (small problems, see mfma_f32_splitk): the grid holds `splits` copies of the tile grid; copy s
-  //      multiplies the k range [s * kChunk, min(K, (s+1) * kChunk)) into its own N x M plane of `partials`, and a second
-  //      kernel adds the planes in ascending s (deterministic).  lda = the row stride of A, which no longer equals K.
-  const unsigned nwg = tiles_n * tiles_m;
-  const unsigned lda = K;
-  unsigned bid = blockIdx.x;
-  if (kChunk) {   // wavefront-uniform
-    const unsigned split = bid / nwg;
-    bid -= split * nwg;
-    const unsigned kbeg = split * kChunk;
-    A += AT ? (size_t)kbeg * N : (size_t)kbeg;
-    B += (size_t)kbeg * M;
-    C = partials + (size_t)split * N * M;
-    K = min(kChunk, K - kbeg);
-  }
-  // ---- workgroup -> output tile: XCD-contiguous chunks, then bands of kBand tile-rows ------------
-  const unsigned lin = xcd_remap(bid, nwg);
-  const unsigned band = lin / (kBand * tiles_m), within = lin % (kBand * tiles_m);
-  const unsigned rows_in_band = min(kBand, tiles_n - band * kBand);
-  const unsigned tile_row = band * kBand + within % rows_in_band;
-  const unsigned tile_col = within / rows_in_band;
-  const unsigned row0 = tile_row * G::BM, col0 = tile_col * G::BN;
 
   // ---- per-lane DMA sources ----------------------------------------------------------------
   // A instruction ja covers LDS 16-B slots [ja*64, ja*64+64): slot -> (row, physical chunk).
@@ -289,14 +266,14 @@ __global__ __launch_bounds__(G::THREADS, G::MIN_WAVES) void mfma_f32_kernel(cons
   // wavefront-uniform) is false for problems whose rows are so long that 64 rows x M x 4 B pass 4 GiB, and those take
   // the predicated forms with 64-bit offsets.
   typedef __attribute__((address_space(1))) f32x4 *gquad_t;
-  const bool interior_block = col0 + wn * 128 + 128 <= M && row0 + wm * TM * 32 + TM * 32 <= N &&
-                              (unsigned long long)(TM * 32) * M * 4ull < (1ull << 32);  // wavefront-uniform
+  const bool interior_block = col0 + wn * 128 + 128 <= Mst && row0 + wm * TM * 32 + TM * 32 <= Nst &&
+                              (unsigned long long)(TM * 32) * ldc * 4ull < (1ull << 32);  // wavefront-uniform
   auto rmw_interior = [&](bool accumulate, auto batchc, auto value) {
     constexpr int BATCH = decltype(batchc)::value;
-    unsigned Mv = M;
+    unsigned Mv = ldc;
     asm volatile("" : "+s"(Mv));  // opaque: the row offsets must not be hoisted out of the chunk loop (they would stay
                                   // live across the main loop and cost it registers)
-    char *base = (char *)(C + (size_t)(row0 + wm * TM * 32) * Mv + col0 + wn * 128);
+    char *base = (char *)(Cst + (size_t)(row0 + wm * TM * 32) * Mv + col0 + wn * 128);
     const unsigned lane_off = ((AT ? TM * 4 * hi : 4 * hi) * Mv + 4 * lo) * 4u;
 #pragma unroll
     for (int mi = 0; mi < TM; ++mi)
@@ -337,8 +314,8 @@ __global__ __launch_bounds__(G::THREADS, G::MIN_WAVES) void mfma_f32_kernel(cons
       for (int r = 0; r < 16; ++r) {
         const unsigned ri = (r & 3) + 8 * (r >> 2) + 4 * hi;
         const unsigned row = row0 + wm * TM * 32 + (AT ? TM * ri + mi : mi * 32 + ri);
-        if (ccol < M && row < N) {
-          f32x4 *dst = (f32x4 *)(C + (size_t)row * M + ccol);
+        if (ccol < Mst && row < Nst) {
+          f32x4 *dst = (f32x4 *)(Cst + (size_t)row * ldc + ccol);
           f32x4 v;
 #pragma unroll
           for (int tt = 0; tt < TN; ++tt) v[tt] = acc[mi][tt][r];
@@ -523,15 +500,15 @@ __global__ __launch_bounds__(G::THREADS, G::MIN_WAVES) void mfma_f32_kernel(cons
       return;
     }
     const unsigned ccol = col0 + wn * 128 + 4 * lo;
-    if (ccol < M) {
+    if (ccol < Mst) {
 #pragma unroll
       for (int mi = 0; mi < TM; ++mi) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const unsigned ri = (r & 3) + 8 * (r >> 2) + 4 * hi;
           const unsigned row = row0 + wm * TM * 32 + (AT ? TM * ri + mi : mi * 32 + ri);
-          if (row < N) {
-            f32x4 *dst = (f32x4 *)(C + (size_t)row * M + ccol);
+          if (row < Nst) {
+            f32x4 *dst = (f32x4 *)(Cst + (size_t)row * ldc + ccol);
             f32x4 v;
 #pragma unroll
             for (int tt = 0; tt < TN; ++tt) {
@@ -547,6 +524,139 @@ __global__ __launch_bounds__(G::THREADS, G::MIN_WAVES) void mfma_f32_kernel(cons
     }
   };
   if (FLUSH && flushed) write_tile(true); else write_tile(false);
+}
+
+template <typename G, bool AT>
+__global__ __launch_bounds__(G::THREADS, G::MIN_WAVES) void mfma_f32_kernel(const float *__restrict__ A,
+                                                              const float *__restrict__ B,
+                                                              float *__restrict__ C, unsigned N,
+                                                              unsigned K, unsigned M,
+                                                              unsigned tiles_n, unsigned tiles_m,
+                                                              unsigned kBand, unsigned kChunk, float *__restrict__ partials) {
+  // ---- split-K launches (small problems, see mfma_f32_splitk): the grid holds `splits` copies of the tile grid; copy s
+  //      multiplies the k range [s * kChunk, min(K, (s+1) * kChunk)) into its own N x M plane of `partials`, and a second
+  //      kernel adds the planes in ascending s (deterministic).  lda = the row stride of A, which no longer equals K.
+  const unsigned nwg = tiles_n * tiles_m;
+  const unsigned lda = K;
+  unsigned bid = blockIdx.x;
+  if (kChunk) {   // wavefront-uniform
+    const unsigned split = bid / nwg;
+    bid -= split * nwg;
+    const unsigned kbeg = split * kChunk;
+    A += AT ? (size_t)kbeg * N : (size_t)kbeg;
+    B += (size_t)kbeg * M;
+    C = partials + (size_t)split * N * M;
+    K = min(kChunk, K - kbeg);
+  }
+  // ---- workgroup -> output tile: XCD-contiguous chunks, then bands of kBand tile-rows ------------
+  const unsigned lin = xcd_remap(bid, nwg);
+  const unsigned band = lin / (kBand * tiles_m), within = lin % (kBand * tiles_m);
+  const unsigned rows_in_band = min(kBand, tiles_n - band * kBand);
+  const unsigned tile_row = band * kBand + within % rows_in_band;
+  const unsigned tile_col = within / rows_in_band;
+  tile_body<G, AT>(A, B, C, N, K, M, lda, M, N, M, tile_row * G::BM, tile_col * G::BN);
+}
+
+// ---- stream-K (round 3): problems of a few partial rounds of tiles ------------------------------------------------
+// A launch runs in whole rounds of resident workgroups, so 2560^3 (400 tiles of 128 x 128 for 512 slots) or 3072^3 (576
+// tiles: one full round and an eighth) leave a large part of the chip idle in their last round.  Here the job's
+// (tile, 32-deep slab) units are dealt out to `gridDim.x` persistent workgroups in equal contiguous ranges; a workgroup
+// walks its range tile by tile.  A tile whose whole K falls into one range is written to C directly; the head and tail
+// tiles of a range are written to the workgroup's two 128 x 128 scratch slots, and a second kernel adds the slots of every
+// split tile in ascending k -- no atomics, same bits run to run.  Needs K % BK == 0 (whole slabs) and row-major A.
+__device__ __forceinline__ unsigned sk_range_begin(unsigned long long units, unsigned w, unsigned nwg) {
+  return (unsigned)(units * w / nwg);
+}
+
+template <typename G>
+__global__ __launch_bounds__(G::THREADS, G::MIN_WAVES) void mfma_f32_streamk_kernel(const float *__restrict__ A,
+                                                                                      const float *__restrict__ B,
+                                                                                      float *__restrict__ C, unsigned N, unsigned K,
+                                                                                      unsigned M, unsigned tiles_n, unsigned tiles_m,
+                                                                                      unsigned kBand, unsigned spt,
+                                                                                      float *__restrict__ slots) {
+  const unsigned nwg = gridDim.x;
+  const unsigned w = xcd_remap(blockIdx.x, nwg);   // an XCD's workgroups own one contiguous stretch of the unit order
+  const unsigned long long units = (unsigned long long)tiles_n * tiles_m * spt;
+  const unsigned u0 = sk_range_begin(units, w, nwg), u1 = sk_range_begin(units, w + 1, nwg);
+  const unsigned first_tile = u0 / spt;
+  for (unsigned u = u0; u < u1;) {
+    const unsigned tile = u / spt, s0 = u - tile * spt, s1 = min(spt, s0 + (u1 - u));
+    const unsigned band = tile / (kBand * tiles_m), within = tile % (kBand * tiles_m);
+    const unsigned rows_in_band = min(kBand, tiles_n - band * kBand);
+    const unsigned row0 = (band * kBand + within % rows_in_band) * G::BM, col0 = (within / rows_in_band) * G::BN;
+    const unsigned kbeg = s0 * G::BK, klen = (s1 - s0) * G::BK;
+    const float *a = A + kbeg, *b = B + (size_t)kbeg * M;
+    if (s0 == 0 && s1 == spt) {
+      tile_body<G, false>(a, b, C, N, klen, M, K, M, N, M, row0, col0);
+    } else {   // head (slot 0) or tail (slot 1) of this workgroup's range: into its scratch slot, addressed like a C with ldc = BN
+      float *slot = slots + ((size_t)w * 2 + (tile != first_tile)) * (G::BM * G::BN);
+      float *base = (float *)((unsigned long long)slot - ((unsigned long long)row0 * G::BN + col0) * sizeof(float));
+      tile_body<G, false>(a, b, base, N, klen, M, K, G::BN, ~0u, ~0u, row0, col0);
+    }
+    u += s1 - s0;
+    __syncthreads();   // the next segment's prologue overwrites the LDS ring
+  }
+}
+
+// C tile = sum of the scratch slots of the workgroups whose ranges cut it, ascending k.  One workgroup per tile; tiles that
+// one range covered whole were written by the main kernel and are skipped.
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void streamk_fixup_kernel(const float *__restrict__ slots, float *__restrict__ C, unsigned N,
+                                                            unsigned M, unsigned tiles_n, unsigned tiles_m, unsigned kBand,
+                                                            unsigned spt, unsigned nwg) {
+  const unsigned tile = blockIdx.x;
+  const unsigned long long units = (unsigned long long)tiles_n * tiles_m * spt;
+  const unsigned u_lo = tile * spt, u_hi = u_lo + spt;
+  unsigned w = (unsigned)((unsigned long long)u_lo * nwg / units);
+  while (w + 1 < nwg && sk_range_begin(units, w + 1, nwg) <= u_lo) ++w;
+  while (w > 0 && sk_range_begin(units, w, nwg) > u_lo) --w;
+  if (sk_range_begin(units, w + 1, nwg) >= u_hi) return;   // one range holds the whole tile
+  const unsigned band = tile / (kBand * tiles_m), within = tile % (kBand * tiles_m);
+  const unsigned rows_in_band = min(kBand, tiles_n - band * kBand);
+  const unsigned row0 = (band * kBand + within % rows_in_band) * BM, col0 = (within / rows_in_band) * BN;
+  constexpr int QUADS = BM * BN / 4 / 256;
+  f32x4 acc[QUADS];
+#pragma unroll
+  for (int i = 0; i < QUADS; ++i) acc[i] = (f32x4)0.0f;
+  for (; w < nwg && sk_range_begin(units, w, nwg) < u_hi; ++w) {
+    const unsigned first_tile = sk_range_begin(units, w, nwg) / spt;
+    const f32x4 *slot = (const f32x4 *)(slots + ((size_t)w * 2 + (tile != first_tile)) * (BM * BN));
+#pragma unroll
+    for (int i = 0; i < QUADS; ++i) acc[i] += slot[i * 256 + threadIdx.x];
+  }
+#pragma unroll
+  for (int i = 0; i < QUADS; ++i) {
+    const unsigned q = i * 256 + threadIdx.x, row = row0 + q / (BN / 4), col = col0 + (q % (BN / 4)) * 4;
+    if (row < N && col < M) *(f32x4 *)(C + (size_t)row * M + col) = acc[i];
+  }
+}
+
+template <typename G>
+int launch_streamk(hipStream_t s, const Problem &p) {
+  const unsigned tiles_n = (p.n + G::BM - 1) / G::BM, tiles_m = (p.m + G::BN - 1) / G::BN, spt = p.k / G::BK;
+  const unsigned nwg = 256 * G::MIN_WAVES;
+  static unsigned long long configured = 0;
+  if (int e = ensure_dynamic_lds((const void *)mfma_f32_streamk_kernel<G>, G::LDS_BYTES, configured)) return e;
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return (int)e;
+  hipMemPool_t pool = nullptr;
+  if (int rc = workspace_pool(dev, &pool)) return rc;
+  float *slots = nullptr;
+  if ((e = hipMallocFromPoolAsync((void **)&slots, (size_t)nwg * 2 * G::BM * G::BN * sizeof(float), pool, s)) != hipSuccess) return (int)e;
+  (void)hipGetLastError();
+  const unsigned kband = band_rows(G::BM, G::BN, G::MIN_WAVES);
+  hipLaunchKernelGGL((mfma_f32_streamk_kernel<G>), dim3(nwg), dim3(G::THREADS), G::LDS_BYTES, s, (const float *)p.a, (const float *)p.b,
+                     (float *)p.c, p.n, p.k, p.m, tiles_n, tiles_m, kband, spt, slots);
+  int rc = (int)hipGetLastError();
+  if (rc == 0) {
+    hipLaunchKernelGGL((streamk_fixup_kernel<G::BM, G::BN>), dim3(tiles_n * tiles_m), dim3(256), 0, s, (const float *)slots, (float *)p.c,
+                       p.n, p.m, tiles_n, tiles_m, kband, spt, nwg);
+    rc = (int)hipGetLastError();
+  }
+  const hipError_t f = hipFreeAsync(slots, s);
+  return rc ? rc : (int)f;
 }
 
 // C = sum over s of partials[s], s ascending: the second kernel of a split-K launch (4 floats per thread)
@@ -636,13 +746,34 @@ int mfma_f32_variant_id(int index) { return index >= 0 && index < mfma_f32_num_v
 // (6144^3: 576 tiles = 2.25 rounds of 256) and small ones leave CUs idle (2048^3: 64 tiles).  Pick
 // the candidate with the smallest estimated time = (workgroups the busiest CU runs) x tile area /
 // relative efficiency.
+static const TileCandidate kAutoCands[] = {{33, 128, 256, 2, 1.00}, {8, 256, 256, 1, 0.991}, {35, 128, 128, 2, 0.993}};
+
+// Stream-K (launch_streamk) against the best whole-tile launch, in pick_tile's units (tile area x workgroups the busiest CU
+// runs one after the other).  Fitted to profiles/r03q_f32_streamk_mid_sizes.txt: the persistent workgroups run 8 % below
+// the whole-tile kernel (segment prologues and epilogues), every split tile costs a scratch write, a read and a share of
+// the fix-up kernel (at most one split tile per workgroup boundary), plus a second launch.  It pays where the last round
+// of whole tiles would leave much of the chip idle -- 2304^3 +28 %, 3072^3 +22 %, 3584^3 +17 %, 2560^3 +9 % -- and is not
+// taken where whole tiles fit (2048^3, 2816^3, 4096^3, 6144^3) nor below a full round's worth of tiles per two CUs
+// (<= 256 tiles: split-K or the plain kernel, see mfma_f32_splitk).  Jobs of more than two rounds of tiles always run whole
+// tiles, which is also what keeps the row slabs of the host-pointer pipeline and of the N-split over GPUs bit-identical to
+// the one-launch result for everything of BASELINE's size.
+static bool streamk_wins(const Problem &p) {
+  if (p.a_transposed || p.k % 32 != 0 || p.k < 256 || p.n_total) return false;
+  const double tiles = (double)((p.n + 127) / 128) * ((p.m + 127) / 128);
+  if (tiles <= 256 || tiles > 1024) return false;   // from two full rounds on, whole tiles lose at most a few % (5120^3: 4 %)
+  double whole = 0;
+  pick_tile(kAutoCands, 3, p.n, p.m, &whole);
+  const double sk = (2.16 * tiles / 512 + 0.24 * (tiles < 512 ? tiles : 512) / 512 + 0.04) * 128 * 128 / 0.993;
+  return sk < 0.97 * whole;
+}
+
 int mfma_f32_auto_variant(const Problem &p) {
   // relative efficiencies at 16384^3 at the end of round 2, all three with the pinned schedule and scalar-base DMA:
   // 128x256 as two 4-wavefront workgroups per CU (33) 152.2 TF, 256x256 / 8 wavefronts (8) 150.8, 128x128x32 (35) 151.2
   // (profiles/r02z_f32_scalar_base_dma.log, r02z_f32_small_tile_scalar_base_dma.log); small and mid-size shapes:
   // r02z_f32_small_shapes_after_scalar_base_dma.log
-  static const TileCandidate cands[] = {{33, 128, 256, 2, 1.00}, {8, 256, 256, 1, 0.991}, {35, 128, 128, 2, 0.993}};
-  return pick_tile(cands, 3, p.n, p.m);
+  if (tuning(TUNE_F32_SPLITK) < 0 && streamk_wins(p)) return 35;   // the 128 x 128 geometry is the one stream-K runs on
+  return pick_tile(kAutoCands, 3, p.n, p.m);
 }
 
 bool mfma_f32_serves(const Problem &p) {
@@ -664,15 +795,19 @@ int mfma_f32_resolve(const Problem &p, int variant) {
 // leave a quarter or more of the CUs without a workgroup (<= 192 tiles), K is cut into S = min(slots / tiles, K / 256, 8) chunks, the S copies of the tile grid run
 // side by side and a second kernel adds the S partial planes in ascending order -- deterministic, run to run and
 // whatever the placement, but a different summation order than the unsplit kernel (as accurate or better: shorter
-// chains).  f32_splitk: -1 this rule, 1 never, 2..8 that many chunks (still only for row-major A and variant 35).
+// chains).  f32_splitk: -1 this rule (and stream-K by streamk_wins), 0 stream-K, 1 neither, 2..8 that many chunks (always only
+// for row-major A and variant 35).  Row slabs of a bigger job (Problem::n_total) never take stream-K: its unit ranges would
+// depend on the slab, and with them a row's summation order.
 int mfma_f32_splitk(const Problem &p, int variant) {
   if (p.a_transposed || variant != 35) return 1;
   const int knob = tuning(TUNE_F32_SPLITK);
+  if (knob == 0) return (p.k % 32 == 0 && p.k >= 64) ? 0 : 1;   // 0 = stream-K (forced by the knob; see launch_streamk)
   const unsigned rows = p.n_total ? p.n_total : p.n;   // of the whole job (Problem::n_total)
   const unsigned long long tiles = (unsigned long long)((rows + 127) / 128) * ((p.m + 127) / 128);
   unsigned s;
   if (knob >= 1) s = (unsigned)knob;
   else if (tuning(TUNE_F32_VARIANT) >= 0) s = 1;          // a pinned geometry is run as pinned
+  else if (streamk_wins(p)) return 0;                     // a few partial rounds of tiles: stream-K
   else s = tiles <= 192 ? (unsigned)(512 / tiles) : 1;   // 256 tiles already give every CU a workgroup (2048^3: 125 vs 112 TF split)
   if (s > 8) s = 8;
   while (s > 1 && p.k / s < 256) --s;                     // chunks of at least 256 k
@@ -705,8 +840,9 @@ int launch_mfma_f32(hipStream_t s, const Problem &p, int variant) {
     case 33: return sdma_fits(p, 16) ? launch_geo<T128x256>(s, p) : launch_geo<T128x256v>(s, p);
     case 8: return sdma_fits(p, 16) ? launch_geo<T256x256>(s, p) : launch_geo<T256x256v>(s, p);
     case 35: {
-      const unsigned splits = (unsigned)mfma_f32_splitk(p, v);
-      return sdma_fits(p, 32) ? launch_geo<T128x128>(s, p, splits) : launch_geo<T128x128v>(s, p, splits);
+      const int splits = mfma_f32_splitk(p, v);
+      if (splits == 0) return sdma_fits(p, 32) ? launch_streamk<T128x128>(s, p) : launch_streamk<T128x128v>(s, p);
+      return sdma_fits(p, 32) ? launch_geo<T128x128>(s, p, (unsigned)splits) : launch_geo<T128x128v>(s, p, (unsigned)splits);
     }
     case 0: return launch_geo<X128x256x32_2lvl>(s, p);
     case 3: return launch_geo<X256x256_single>(s, p);
