@@ -23,7 +23,7 @@ EXPORTS = ["mm_init", "mm_alloc", "mm_free", "mm_copy_to_device", "mm_copy_to_ho
            "mm_fill_device", "mm_gemm_launch", "mm_gemm_enqueue", "mm_gemm_multi_device",
            "MatrixMultiplicationKernel", "mm_set_default_config", "mm_dtype_size",
            "mm_config_supported", "mm_kernel_name", "mm_kernel_info", "mm_last_error",
-           "mm_gemm_host", "mm_tuning_set", "mm_tuning_get", "mm_release_workspace"]
+           "mm_gemm_host", "mm_tuning_set", "mm_tuning_get", "mm_release_workspace", "mm_device_pci_bus_id"]
 
 
 class MMError(RuntimeError):
@@ -88,6 +88,7 @@ def lib():
         L.mm_tuning_set.argtypes = [ctypes.c_char_p, i]
         L.mm_tuning_get.argtypes = [ctypes.c_char_p, ctypes.POINTER(i)]
         L.mm_release_workspace.argtypes = [i]
+        L.mm_device_pci_bus_id.argtypes = [i, ctypes.c_char_p, i]
         _lib = L
     return _lib
 

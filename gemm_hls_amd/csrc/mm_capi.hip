@@ -154,6 +154,9 @@ int dispatch(hipStream_t s, const mm_config_t &cfg, const mm::Problem &p) {
   if (fam != FAM_ORDERED && fam != FAM_HALF_WIDE && fam != FAM_F32_SPLIT && !aligned16(p))
     return fail(MM_ERR_BAD_ARGUMENT, "a, b and c must be 16-byte aligned for the fast path (got %p, %p, %p); "
                 "use an aligned allocation or MM_PATH_ORDERED", p.a, p.b, p.c);
+  // the launchers report hipGetLastError() after their launch: a stale (sticky-until-read) error of the application's own
+  // earlier HIP calls on this thread must not be reported as this launch's
+  (void)hipGetLastError();
   int e;
   switch (fam) {
     case FAM_MFMA_F32: e = mm::launch_mfma_f32(s, p, f32_variant()); break;
@@ -275,6 +278,14 @@ int mm_release_workspace(int device) {
   MM_HIP(hipSetDevice(device));
   MM_HIP(hipDeviceSynchronize());   // stream-ordered frees are complete: everything the pool holds is reclaimable
   MM_HIP((hipError_t)mm::workspace_release(device));
+  return MM_OK;
+}
+
+int mm_device_pci_bus_id(int device, char *buffer, int length) {
+  int rc = check_device(device);
+  if (rc) return rc;
+  if (!buffer || length < 13) return fail(MM_ERR_BAD_ARGUMENT, "mm_device_pci_bus_id needs a buffer of at least 13 bytes");
+  MM_HIP(hipDeviceGetPCIBusId(buffer, length, device));
   return MM_OK;
 }
 
@@ -612,7 +623,11 @@ int mm_kernel_info(const mm_config_t *cfg, unsigned n, unsigned k, unsigned m, m
       break;
     }
     case FAM_F32_SPLIT:
-      r.tile_n = r.tile_m = (unsigned)mm::mfma_f32_split_tile(p, mm::tuning(mm::TUNE_SPLIT_VARIANT));
+      {  // the 128 x 128 geometry runs only in the launcher's default branch (no schedule / product / flush bits set)
+        const int sv = mm::tuning(mm::TUNE_SPLIT_VARIANT);
+        const bool plain = sv <= 0 || (sv & (1 | 2 | 4 | 64 | 128)) == 0;
+        r.tile_n = r.tile_m = plain ? (unsigned)mm::mfma_f32_split_tile(p, sv) : 256u;
+      }
       r.tile_k = 16; r.wavefronts = r.tile_n == 256 ? 8 : 4;
       r.inst_n = 32; r.inst_m = 32; r.inst_k = 16;
       r.ops_per_clk_per_cu = 4096.0 / 6.0;  // six bf16 MFMAs per fp32 multiply-add block

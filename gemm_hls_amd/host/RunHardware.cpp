@@ -157,7 +157,7 @@ int main(int argc, char **argv) {
 #ifdef MM_POWER_METER
     double average_power = 0.0;
     size_t power_samples = 0;
-    std::string power_source = "no single-device launch";
+    std::string power_source = "no single-device launch", power_bdf = "?";
 #endif
     if (gpus > 1) {
       std::cout << "Initializing device memory on " << gpus << " devices, copying row slabs of A and C and replicas of B...\n"
@@ -184,7 +184,9 @@ int main(int argc, char **argv) {
         Check(mm_gemm_launch(0, &cfg, aDevice.ptr, bDevice.ptr, cDevice.ptr, size_n, size_k, size_m, nullptr), "warm-up");
       }
 #ifdef MM_POWER_METER
-      mmhost::PowerMeter pm(0, 2);  // device 0, 2 ms sampling period (the reference samples its PSU every 10 ms)
+      char bdf[32] = {0};
+      if (mm_device_pci_bus_id(0, bdf, sizeof bdf) != MM_OK) bdf[0] = 0;
+      mmhost::PowerMeter pm(0, 2, bdf);  // HIP device 0 by PCI address, 2 ms sampling period (the reference samples its PSU every 10 ms)
       pm.Start();
 #endif
       Check(mm_gemm_launch(0, &cfg, aDevice.ptr, bDevice.ptr, cDevice.ptr, size_n, size_k, size_m, &elapsed),
@@ -202,6 +204,7 @@ int main(int argc, char **argv) {
       average_power = pm.Average();
       power_samples = pm.Samples();
       power_source = pm.Source();
+      power_bdf = bdf[0] ? bdf : "unknown";
 #endif
       if (verify) {
         std::cout << "Copying back result...\n" << std::flush;
@@ -227,7 +230,7 @@ int main(int argc, char **argv) {
     // the reference's line (host/RunHardware.cpp:182-185) up to "W": scripts/build_manager.py:603-604
     // parses "([\\d\\.]+) W"; what was measured is this GPU's board power, not "the full system"
     std::cout << "Measured an average power of " << average_power << " W for the GPU (" << power_samples << " samples, "
-              << power_source << ").\n";
+              << power_source << ", PCI " << power_bdf << ").\n";
 #endif
   } catch (std::runtime_error const &err) {
     std::cerr << "Execution failed with error: \"" << err.what() << "\"." << std::endl;

@@ -108,10 +108,16 @@ int mm_alloc(int device, size_t bytes, void **device_ptr);
 int mm_free(int device, void *device_ptr);
 
 /* buffer.CopyFromHost / CopyToHost (RunHardware.cpp:142-144,189).  Blocking. */
-/* MM_PATH_SPLIT keeps its workspace (6 bytes per element of A and B of the largest launch so far) cached in
- * the device's default stream-ordered memory pool between launches.  This waits for the device and hands
- * that memory back to the driver; the next MM_PATH_SPLIT launch allocates again. */
+/* Stream-ordered workspace (MM_PATH_SPLIT: 6 bytes per element of A and B of the largest launch so far; the fp32
+ * default path: the partial planes / scratch slots of its split-K and stream-K launches, a few MiB) is cached between
+ * launches in a memory pool this library owns -- never in the process's default pool.  This waits for the device and
+ * hands that memory back to the driver; the next launch that needs workspace allocates again. */
 int mm_release_workspace(int device);
+
+/* The PCI address ("0000:c1:00.0") of HIP device `device`, for tools that must find the same physical GPU through
+ * an interface that does not honour HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES (ROCm SMI, sysfs): the runner's
+ * power meter (the reference's PowerMeter role, host/RunHardware.cpp:156-172). */
+int mm_device_pci_bus_id(int device, char *buffer, int length);
 
 int mm_copy_to_device(int device, void *device_dst, const void *host_src, size_t bytes);
 int mm_copy_to_host(int device, void *host_dst, const void *device_src, size_t bytes);
