@@ -230,13 +230,57 @@ __global__ __launch_bounds__(512) void k3(float *out, unsigned long long *cyc, i
   if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 8 + (threadIdx.x >> 6)] = t1 - t0;
 }
 
+// Accumulators in AGPRs vs VGPRs (unified file on gfx950, but the operand paths differ): 16x16x32 f16, 8x4 block, the MFMAs
+// written in inline asm with the accumulator constrained to the accumulation registers ("a") or the vector registers ("v").
+template <bool AGPR>
+__global__ __launch_bounds__(512) void k4(float *out, unsigned long long *cyc, int iters) {
+  unsigned st = threadIdx.x * 2654435761u + blockIdx.x * 40503u + 12345u;
+  constexpr int TA = 8, TB = 4;
+  h8 a[2][TA], b[2][TB];
+  f32x4 acc[TA][TB];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+#pragma unroll
+    for (int i = 0; i < TA; ++i) a[q][i] = rnd8(st);
+#pragma unroll
+    for (int i = 0; i < TB; ++i) b[q][i] = rnd8(st);
+  }
+#pragma unroll
+  for (int i = 0; i < TA; ++i)
+#pragma unroll
+    for (int j = 0; j < TB; ++j) acc[i][j] = (f32x4)0.0f;
+  __syncthreads();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int i = 0; i < TA; ++i)
+#pragma unroll
+        for (int j = 0; j < TB; ++j) {
+          if constexpr (AGPR) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(a[q][i]), "v"(b[q][j]));
+          else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[i][j]) : "v"(a[q][i]), "v"(b[q][j]));
+        }
+  }
+  float s = 0;
+#pragma unroll
+  for (int i = 0; i < TA; ++i)
+#pragma unroll
+    for (int j = 0; j < TB; ++j) s += acc[i][j][0];
+  asm volatile("s_nop 0" ::"v"(s) : "memory");
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  out[blockIdx.x * 512 + threadIdx.x] = s;
+  if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 8 + (threadIdx.x >> 6)] = t1 - t0;
+}
+
 template <int MODE>
 int run(const char *name, int mfma_per_iter, double flop_per_mfma, float *d, unsigned long long *dc) {
   const int blocks = 256, iters = 1 << 17;
   hipEvent_t e0, e1;
   CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
   auto launch = [&]() {
-    if constexpr (MODE >= 20) k3<MODE - 20><<<blocks, 512>>>(d, dc, iters / 8);
+    if constexpr (MODE >= 30) k4<MODE == 31><<<blocks, 512>>>(d, dc, iters);
+    else if constexpr (MODE >= 20) k3<MODE - 20><<<blocks, 512>>>(d, dc, iters / 8);
     else if constexpr (MODE >= 10) k2<MODE - 10><<<blocks, 512>>>(d, dc, iters);
     else k<MODE><<<blocks, 512>>>(d, dc, iters);
   };
@@ -251,7 +295,7 @@ int run(const char *name, int mfma_per_iter, double flop_per_mfma, float *d, uns
   CHECK(hipMemcpy(c.data(), dc, c.size() * 8, hipMemcpyDeviceToHost));
   unsigned long long mx = 0;
   for (auto v : c) mx = std::max(mx, v);
-  const double inst = (double)(MODE >= 20 ? iters / 8 : iters) * mfma_per_iter;   // per wave
+  const double inst = (double)((MODE >= 20 && MODE < 30) ? iters / 8 : iters) * mfma_per_iter;   // per wave
   const double tops = 256.0 * 8 * inst * flop_per_mfma / (ms * 1e-3) / 1e12;
   printf("%-58s %7.1f TF  clock >= %5.3f GHz  %6.2f cyc/MFMA/SIMD  %7.2f ms\n", name, tops, (double)mx / (ms * 1e6),
          (double)mx / (inst * 2), ms);
@@ -272,6 +316,8 @@ int main() {
     run<11>("i8 16x16x64, 8x4 block", 64, 32768, d, dc);
     run<12>("bf16 32x32x16, 4x2 block", 16, 32768, d, dc);
     run<13>("bf16 16x16x32, 8x4 block", 64, 16384, d, dc);
+    run<30>("f16 16x16x32 (asm), accumulators in VGPRs", 64, 16384, d, dc);
+    run<31>("f16 16x16x32 (asm), accumulators in AGPRs", 64, 16384, d, dc);
     run<20>("f32 32x32x2, 2x4 block", 32, 4096, d, dc);
     run<21>("f32 16x16x4, 4x8 block", 128, 2048, d, dc);
   }
