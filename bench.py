@@ -78,6 +78,15 @@ MFMA_SUSTAINED = {
 }
 
 
+# What the VALU sustains on the fp64 min-plus instruction pair (tools/probes/probe_valu_rate.hip, cycles measured with s_memtime):
+# v_add_f64 / v_min_f64 issue every 4.26 cycles at 4 waves per SIMD (4.51 at the 2 waves this kernel's 128 accumulator
+# registers allow), not every 4.0 as the nominal 39.3 TOp/s `peak` assumes.
+VALU_SUSTAINED = {
+    "minplus_f64": {"probe_mix_TOps_4_waves_per_simd": 35.2, "probe_mix_TOps_2_waves_per_simd": 32.7, "clock_GHz": 2.36,
+                    "source": "profiles/r03s_probe_valu_issue_rates_incl_f64.txt"},
+}
+
+
 def cpu_baseline(sample_n=1024):
     """The repo's own hlslib simulation path (reference kernel sources + test-only shim) on
     float sample_n^3; this is the checker's side of the house, never the product."""
@@ -241,6 +250,8 @@ def extra_workloads(g, torch, dev, local_rank, steps=5):
                      "ms_per_step": round(1e3 * elapsed / steps, 4),
                      "roofline": roofline_obj(dtype, roof, peak, rows, k, m, launch_ms)}
             attach_replayed(entry["roofline"], entry["kernel"], (rows, k, m))
+            if key in VALU_SUSTAINED:
+                entry["roofline"]["valu_sustained"] = VALU_SUSTAINED[key]
             if key == "float_split":
                 entry["workload"] += "; MM_PATH_SPLIT (opt-in), split + re-tile pre-pass inside the timed step"
                 entry["dtype"] = "f32 in/out; operands as 3 bf16 planes, 6 bf16 MFMA products per pair, f32 accumulate"

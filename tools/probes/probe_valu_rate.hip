@@ -24,6 +24,9 @@ template <int MODE>
 __global__ __launch_bounds__(1024) void k(float *out, unsigned long long *cyc, float x, float y) {
   float a[16];
   f2 p[8];
+  double da[16];   // fp64 modes (round 3: the DMA-staged VALU kernel serves double min-plus)
+  for (int i = 0; i < 16; ++i) da[i] = threadIdx.x + i;
+  const double dx = x, dy = y;
   for (int i = 0; i < 16; ++i) a[i] = threadIdx.x + i;
   for (int i = 0; i < 8; ++i) p[i] = f2{(float)threadIdx.x, (float)i};
   const f2 xy = {x, y};
@@ -41,6 +44,13 @@ __global__ __launch_bounds__(1024) void k(float *out, unsigned long long *cyc, f
       if (MODE == 6) asm volatile("v_max_f32 %0, %0, %1" : "+v"(a[i]) : "v"(x));
       if (MODE == 7) asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[i]) : "v"(x));
       if (MODE == 8) asm volatile("v_min_u32 %0, %0, %1" : "+v"(a[i]) : "v"(x));
+      if (MODE == 11) asm volatile("v_add_f64 %0, %0, %1" : "+v"(da[i]) : "v"(dx));
+      if (MODE == 12) asm volatile("v_min_f64 %0, %0, %1" : "+v"(da[i]) : "v"(dx));
+      if (MODE == 13) {   // the double min-plus step: add into a temporary, min into the accumulator (there is no v_min3_f64)
+        double s0;
+        asm volatile("v_add_f64 %0, %1, %2" : "=v"(s0) : "v"(dx), "v"(da[(i + 1) & 15]));
+        asm volatile("v_min_f64 %0, %0, %1" : "+v"(da[i]) : "v"(s0));
+      }
       // the float min-plus inner loop as valu_tile compiles it: per accumulator and pair of k-steps
       // two adds into temporaries and ONE v_min3 (acc, s0, s1): 3 instructions per 4 operations
       if (MODE == 9) {
@@ -64,6 +74,7 @@ __global__ __launch_bounds__(1024) void k(float *out, unsigned long long *cyc, f
   float s = 0;
   for (int i = 0; i < 16; ++i) s += a[i];
   for (int i = 0; i < 8; ++i) s += p[i][0] + p[i][1];
+  for (int i = 0; i < 16; ++i) s += (float)da[i];
   out[blockIdx.x * 1024 + threadIdx.x] = s;
   if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 16 + (threadIdx.x >> 6)] = t1 - t0;
 }
@@ -119,6 +130,9 @@ int main() {
     run<8>("v_min_u32", 1, 0, wps, d, dc);
     run<9>("min-plus mix: 2 v_add + 1 v_min3", 3, 4, wps, d, dc);
     run<10>("min-plus mix: 2 v_add + 2 v_min", 4, 4, wps, d, dc);
+    run<11>("v_add_f64", 1, 0, wps, d, dc);
+    run<12>("v_min_f64", 1, 0, wps, d, dc);
+    run<13>("fp64 min-plus: v_add_f64 + v_min_f64", 2, 2, wps, d, dc);
   }
   return 0;
 }
