@@ -456,7 +456,9 @@ int launch_gemm(hipStream_t s, const char *ap, const char *bp, const Problem &p,
 
 }  // namespace
 
-bool mfma_f32_split_serves(const Problem &p) { return p.n > 0 && p.m > 0 && p.k > 0; }
+// (the write-back addresses up to 131 rows x M x 4 B from a wavefront's first row with 32-bit offsets: rows of C beyond
+// 8 Mi floats are not served -- ADVICE r2)
+bool mfma_f32_split_serves(const Problem &p) { return p.n > 0 && p.m > 0 && p.k > 0 && 132ull * p.m * 4ull < (1ull << 32); }
 
 // 256 x 256 (ping-pong, one workgroup per CU) or 128 x 128 (two workgroups per CU) for problems whose 256-tiles
 // would leave compute units idle; same estimator as the other families (mm_common.h).  variant bit 8 (256) pins 256,

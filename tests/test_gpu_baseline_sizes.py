@@ -280,3 +280,26 @@ def test_c1_float_1024_device_next_to_the_reference_kernel_itself():
     assert bad == 0, (bad, first, worst)
     # the reference's own acceptance rule for this path (TestSimulation: 1e-3 against ReferenceImplementation)
     assert _oracle.compare("float", c_ref, _oracle.naive("float", "Multiply", "Add", a, b), 1e-3)[0] == 0
+
+
+def test_f32_rows_of_c_longer_than_the_32_bit_reach_of_the_interior_write_back():
+    """the straight-line interior write-back of the shipped fp32 geometries addresses C with 32-bit
+    byte offsets from a wavefront's first row (up to 64 rows x M x 4 B).  With M = 17 Mi floats that passes 4 GiB; the
+    kernel must notice (wavefront-uniform guard) and take the 64-bit predicated path instead of wrapping around."""
+    import torch
+    n, k, m = 192, 16, 17 * 1024 * 1024
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    a = torch.empty((n, k), dtype=torch.float32, device="cuda").uniform_(1, 10, generator=gen)
+    b = torch.empty((k, m), dtype=torch.float32, device="cuda").uniform_(1, 10, generator=gen)
+    for variant in (-1, 8, 35):
+        g.set_tuning("f32_variant", variant)
+        c = g.matmul(a, b)
+        g.set_tuning("f32_variant", -1)
+        cols = torch.tensor([0, 1, 4095, 8 * 1024 * 1024 + 5, 16 * 1024 * 1024 - 1, 16 * 1024 * 1024, m - 4, m - 1], device="cuda")
+        want = a.double() @ b[:, cols].double()
+        got = c[:, cols].double()
+        assert float(((got - want).abs() / want).max()) < 1e-5, variant
+        # and every row block got its own data: row r of C depends on row r of A only
+        assert float((c[100, ::65537].double() - (a[100].double() @ b[:, ::65537].double())).abs().max() / 1e3) < 1e-5
+        del c
+    torch.cuda.empty_cache()
