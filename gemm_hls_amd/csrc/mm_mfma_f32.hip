@@ -620,6 +620,7 @@ __global__ __launch_bounds__(256) void streamk_fixup_kernel(const float *__restr
 #pragma unroll
   for (int i = 0; i < QUADS; ++i) acc[i] = (f32x4)0.0f;
   for (; w < nwg && sk_range_begin(units, w, nwg) < u_hi; ++w) {
+    if (sk_range_begin(units, w + 1, nwg) == sk_range_begin(units, w, nwg)) continue;   // an empty range (fewer units than workgroups) wrote nothing
     const unsigned first_tile = sk_range_begin(units, w, nwg) / spt;
     const f32x4 *slot = (const f32x4 *)(slots + ((size_t)w * 2 + (tile != first_tile)) * (BM * BN));
 #pragma unroll

@@ -241,3 +241,88 @@ def test_the_model_catches_a_wrong_count():
         waves.append(w)
     with pytest.raises(AssertionError):
         check(waves, lambda slab: slab % 4)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Stream-K unit ranges (gemm_hls_amd/csrc/mm_mfma_f32.hip: mfma_f32_streamk_kernel / streamk_fixup_kernel), replayed on
+# the CPU with the kernels' own integer formulas: every (tile, slab) unit is multiplied exactly once, a workgroup writes at
+# most one head and one tail slot, and the fix-up of a tile adds exactly the slots that were written for it, in ascending k.
+def _sk_begin(units, w, nwg):
+    return units * w // nwg
+
+
+def _streamk_main(tiles, spt, nwg):
+    """What the main kernel does: returns (direct: {tile}, slots: {(w, which): (tile, s0, s1)})."""
+    units = tiles * spt
+    direct, slots, covered = set(), {}, {}
+    for w in range(nwg):
+        u0, u1 = _sk_begin(units, w, nwg), _sk_begin(units, w + 1, nwg)
+        first_tile = u0 // spt
+        u = u0
+        while u < u1:
+            tile = u // spt
+            s0 = u - tile * spt
+            s1 = min(spt, s0 + (u1 - u))
+            for sl in range(s0, s1):
+                assert (tile, sl) not in covered
+                covered[(tile, sl)] = w
+            if s0 == 0 and s1 == spt:
+                assert tile not in direct
+                direct.add(tile)
+            else:
+                key = (w, int(tile != first_tile))
+                assert key not in slots, "a workgroup reused a scratch slot"
+                slots[key] = (tile, s0, s1)
+            u += s1 - s0
+    assert len(covered) == units
+    return direct, slots
+
+
+def _streamk_fixup(tile, tiles, spt, nwg):
+    """What the fix-up workgroup of `tile` reads: None if one range holds the whole tile, else the slot keys in order."""
+    units = tiles * spt
+    u_lo, u_hi = tile * spt, tile * spt + spt
+    w = u_lo * nwg // units
+    while w + 1 < nwg and _sk_begin(units, w + 1, nwg) <= u_lo:
+        w += 1
+    while w > 0 and _sk_begin(units, w, nwg) > u_lo:
+        w -= 1
+    if _sk_begin(units, w + 1, nwg) >= u_hi:
+        return None
+    keys = []
+    while w < nwg and _sk_begin(units, w, nwg) < u_hi:
+        if _sk_begin(units, w + 1, nwg) != _sk_begin(units, w, nwg):   # an empty range (fewer units than workgroups) wrote nothing
+            first_tile = _sk_begin(units, w, nwg) // spt
+            keys.append((w, int(tile != first_tile)))
+        w += 1
+    return keys
+
+
+@pytest.mark.parametrize("tiles,spt,nwg", [(324, 72, 512), (400, 80, 512), (576, 96, 512), (784, 8, 512), (64, 32, 512), (1, 3, 512),
+                                           (513, 1, 512), (1000, 7, 512), (7, 1000, 512), (257, 33, 512), (1024, 128, 512), (3, 2, 8)])
+def test_streamk_ranges_cover_every_unit_once_and_fixup_reads_what_was_written(tiles, spt, nwg):
+    direct, slots = _streamk_main(tiles, spt, nwg)
+    by_tile = {}
+    for key, (tile, s0, s1) in slots.items():
+        by_tile.setdefault(tile, []).append((s0, s1, key))
+    for tile in range(tiles):
+        keys = _streamk_fixup(tile, tiles, spt, nwg)
+        if tile in direct:
+            assert keys is None and tile not in by_tile      # written to C by the main kernel, nothing to add
+            continue
+        segs = sorted(by_tile[tile])
+        assert keys == [k for _, _, k in segs]               # exactly the written slots, in ascending k
+        assert segs[0][0] == 0 and segs[-1][1] == spt and all(a[1] == b[0] for a, b in zip(segs, segs[1:]))
+
+
+def test_streamk_ranges_random_configurations():
+    import random
+    rnd = random.Random(7)
+    for _ in range(300):
+        tiles, spt, nwg = rnd.randint(1, 1500), rnd.randint(1, 200), rnd.choice([8, 64, 256, 512])
+        direct, slots = _streamk_main(tiles, spt, nwg)
+        split = {t for (t, _, _) in slots.values()}
+        assert not (split & direct) and len(split | direct) == tiles
+        for tile in rnd.sample(sorted(split), min(20, len(split))):
+            keys = _streamk_fixup(tile, tiles, spt, nwg)
+            assert keys == [k for _, _, k in sorted((s0, s1, k) for k, (t, s0, s1) in slots.items() if t == tile)]
