@@ -205,12 +205,15 @@ typedef struct {
 } mm_kernel_info_t;
 int mm_kernel_info(const mm_config_t *cfg, unsigned size_n, unsigned size_k, unsigned size_m,
                    mm_kernel_info_t *info);
-/* Tuning knobs for sweeps and ablations ("f32_variant", "f64_variant", "f16_variant",
- * "i8_variant", "valu_variant", "split_variant", "band_rows"; -1 = the library's own choice; "ablations" = 1 unlocks the
- * measurement-only variants that skip work and therefore return wrong results).  Each is initialised ONCE from its
- * environment variable (MM_F32_VARIANT, ...) and changed only through this call afterwards; the
- * launch path never reads the environment.  No reference counterpart (the reference's tile sizes
- * are CMake cache variables, CMakeLists.txt:18-20). */
+/* Tuning knobs for sweeps ("f32_variant", "f64_variant", "f16_variant", "i8_variant", "valu_variant", "split_variant",
+ * "band_rows", "f32_splitk"; -1 = the library's own choice).  Kernel ids of this library: f32_variant 33 / 8 / 35 (the
+ * geometries of the shape-adaptive pick) and 0 / 3 (cross-checks); f16_variant 200 / 100 / 11 / 0 / 4; i8_variant 200 /
+ * 100 / 10 / 0; f64_variant 0-3; f32_splitk 0 stream-K, 1 whole tiles, 2-8 K chunks.  Any other id is refused: the retired
+ * schedules and the work-skipping ablations of the measurement history exist only in the lab build
+ * (tools/lab/libmm_gemm_amd_lab.so, where "ablations" = 1 unlocks the latter).  Each knob is initialised ONCE from its
+ * environment variable (MM_F32_VARIANT, ...) and changed only through this call afterwards; the launch path never reads
+ * the environment.  The reference's counterpart is the build-time tile knob (CMakeLists.txt:18-20), which the host
+ * binaries honour through -DMM_MEMORY_TILE_SIZE_N / _M (host/HostConfig.h: ApplyBuildTimeTile). */
 int mm_tuning_set(const char *name, int value);
 int mm_tuning_get(const char *name, int *value);
 /* Message of the last failing call on this thread (static or thread-local storage). */
