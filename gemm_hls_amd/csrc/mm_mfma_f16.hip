@@ -310,7 +310,6 @@ __global__ __launch_bounds__(G::THREADS) void mfma_f16_kernel(const _Float16 *__
 //   B slab image [32 k][256 cols]: chunk index ^ (k&3)<<2 ^ ((k>>3)&1)<<1.
 struct GeoPP {
   static constexpr int BM = 256, BN = 256, BK = 32, NS = 4, THREADS = 512;
-  static constexpr int TM = 4, TN = 2;  // 128 x 64 per wave
   static constexpr int A_BYTES = BM * BK * 2, B_BYTES = BK * BN * 2, STAGE_BYTES = A_BYTES + B_BYTES;
   static constexpr int LDS_BYTES = NS * STAGE_BYTES;  // 128 KiB; the epilogue needs 8 x 128 x 128 B = 128 KiB
   static constexpr int BROW = BN * 2;

@@ -258,7 +258,6 @@ __global__ __launch_bounds__(GeoI8::THREADS) void mfma_i8_kernel(const signed ch
 // Requirements: K % 64 == 0 (the reference's contract for 1-byte types), M % 16 == 0, row-major A.
 struct GeoI8PP {
   static constexpr int BM = 256, BN = 256, BK = 64, NS = 4, THREADS = 512;
-  static constexpr int TM = 4, TN = 2;
   static constexpr int A_BYTES = BM * BK, B_BYTES = BK * BN, STAGE_BYTES = A_BYTES + B_BYTES;
   static constexpr int LDS_BYTES = NS * STAGE_BYTES;
   static constexpr int BROW = BN;
