@@ -768,8 +768,10 @@ __global__ __launch_bounds__(GeoPP2::THREADS) void mfma_f16_pp2s_kernel(const _F
     const unsigned lc = pb ^ ((kr & 3u) << 2) ^ (((kr >> 3) & 1u) << 1);
     voff_b[i] = kr * M * 2 + (min(col0 + lc * 8, M - 8) - col0) * 2;
   }
-  const char *a_base = (const char *)A + (size_t)row0 * K * 2;
-  const char *b_base = (const char *)B + (size_t)col0 * 2;
+  // ABLATIONS (wrong results on purpose; power breakdown of the 16x16x32 kernel): VAR bit 4 = no DMA in the main loop, bit 5 =
+  // no fragment reads in the main loop (the first slab's are reused), bit 6 = every workgroup streams tile (0, 0)'s panels
+  const char *a_base = (const char *)A + ((VAR & 64) ? 0 : (size_t)row0 * K * 2);
+  const char *b_base = (const char *)B + ((VAR & 64) ? 0 : (size_t)col0 * 2);
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
   const unsigned U = K / G::BK, UD = U / 2;
 #define MM_PP2_ISSUE(V0, V1, SB, L0, L1)                                                                   \
@@ -812,6 +814,7 @@ __global__ __launch_bounds__(GeoPP2::THREADS) void mfma_f16_pp2s_kernel(const _F
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) acc[rb][nb] = (f32x4)0.0f;
 
+  h8 af_keep[RB], bf_keep[NB];   // ablation bit 5 only
   auto sync = [&]() {
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
@@ -823,6 +826,12 @@ __global__ __launch_bounds__(GeoPP2::THREADS) void mfma_f16_pp2s_kernel(const _F
     const char *abase = smem + abuf * G::A2_BYTES;
     const char *bbase = smem + BUF * G::B_BYTES;
     h8 af[RB], bf[NB];
+    if ((VAR & 32) && u > 0) {
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) bf[nb] = bf_keep[nb];
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) af[rb] = af_keep[rb];
+    } else {
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
       const char *p = bbase + b_off[nb];
@@ -832,9 +841,18 @@ __global__ __launch_bounds__(GeoPP2::THREADS) void mfma_f16_pp2s_kernel(const _F
     }
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) af[rb] = *(const h8 *)(abase + a_off[H] + rb * 16 * 128);
+    if (VAR & 32) {
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) bf_keep[nb] = bf[nb];
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) af_keep[rb] = af[rb];
+    }
+    }
     const unsigned abuf_fill = abuf >= 1 ? abuf - 1 : 2;
-    issue_a(u / 2 + 2, abuf_fill, H);
-    issue_b(u + 3, (BUF + 3) & 3);
+    if (!(VAR & 16)) {
+      issue_a(u / 2 + 2, abuf_fill, H);
+      issue_b(u + 3, (BUF + 3) & 3);
+    }
     asm volatile("s_waitcnt vmcnt(8)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
     sync();
     __builtin_amdgcn_s_setprio(1);
@@ -1180,6 +1198,13 @@ int launch_mfma_f16(hipStream_t s, const Problem &p) {
   if (v == 302 && mfma_f16_pp_serves(p)) return launch_pp3<2>(s, p);
   if (v == 200 && mfma_f16_pp2_serves(p)) return launch_pp2s<0>(s, p);   // 16x16x32 matrix instruction
   if (v == 202 && mfma_f16_pp2_serves(p)) return launch_pp2s<2>(s, p);   // its lock-step ablation
+  if ((v == 216 || v == 232 || v == 248 || v == 264) && mfma_f16_pp2_serves(p)) {   // ablations of the 16x16x32 kernel
+    if (tuning(TUNE_ABLATIONS) != 1) return kErrNotSupported;
+    if (v == 216) return launch_pp2s<16>(s, p);   // no DMA
+    if (v == 232) return launch_pp2s<32>(s, p);   // no fragment reads
+    if (v == 248) return launch_pp2s<48>(s, p);   // neither
+    return launch_pp2s<64>(s, p);                 // L2-resident sources
+  }
   if (v >= 100 && v < 200 && mfma_f16_pp2_serves(p)) {  // 100 + VAR of the full-line-A ping-pong kernel
     switch (v - 100) {
       case 0: return launch_pp2<0>(s, p);
