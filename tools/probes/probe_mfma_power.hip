@@ -273,13 +273,64 @@ __global__ __launch_bounds__(512) void k4(float *out, unsigned long long *cyc, i
   if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 8 + (threadIdx.x >> 6)] = t1 - t0;
 }
 
+// The K = 16 form of the 16x16 bf16 instruction (v_mfma_f32_16x16x16_bf16, 4 bf16 per lane and operand): 8x4 block, the
+// candidate for MM_PATH_SPLIT's kernel, whose 16-deep packed slabs it could consume without a new layout.
+typedef short s4v __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(512) void k5(float *out, unsigned long long *cyc, int iters) {
+  unsigned st = threadIdx.x * 2654435761u + blockIdx.x * 40503u + 12345u;
+  constexpr int TA = 8, TB = 4;
+  s4v a[2][TA], b[2][TB];
+  f32x4 acc[TA][TB];
+  auto rnd = [&]() {
+    s4v v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      st = st * 1664525u + 1013904223u;
+      const float f = 1.0f + 9.0f * (st >> 8) * (1.0f / 16777216.0f);
+      v[j] = (short)(__builtin_bit_cast(unsigned, f) >> 16);
+    }
+    return v;
+  };
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+#pragma unroll
+    for (int i = 0; i < TA; ++i) a[q][i] = rnd();
+#pragma unroll
+    for (int i = 0; i < TB; ++i) b[q][i] = rnd();
+  }
+#pragma unroll
+  for (int i = 0; i < TA; ++i)
+#pragma unroll
+    for (int j = 0; j < TB; ++j) acc[i][j] = (f32x4)0.0f;
+  __syncthreads();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int i = 0; i < TA; ++i)
+#pragma unroll
+        for (int j = 0; j < TB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a[q][i], b[q][j], acc[i][j], 0, 0, 0);
+  }
+  float s = 0;
+#pragma unroll
+  for (int i = 0; i < TA; ++i)
+#pragma unroll
+    for (int j = 0; j < TB; ++j) s += acc[i][j][0];
+  asm volatile("s_nop 0" ::"v"(s) : "memory");
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  out[blockIdx.x * 512 + threadIdx.x] = s;
+  if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 8 + (threadIdx.x >> 6)] = t1 - t0;
+}
+
 template <int MODE>
 int run(const char *name, int mfma_per_iter, double flop_per_mfma, float *d, unsigned long long *dc) {
   const int blocks = 256, iters = 1 << 17;
   hipEvent_t e0, e1;
   CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
   auto launch = [&]() {
-    if constexpr (MODE >= 30) k4<MODE == 31><<<blocks, 512>>>(d, dc, iters);
+    if constexpr (MODE == 40) k5<<<blocks, 512>>>(d, dc, iters);
+    else if constexpr (MODE >= 30) k4<MODE == 31><<<blocks, 512>>>(d, dc, iters);
     else if constexpr (MODE >= 20) k3<MODE - 20><<<blocks, 512>>>(d, dc, iters / 8);
     else if constexpr (MODE >= 10) k2<MODE - 10><<<blocks, 512>>>(d, dc, iters);
     else k<MODE><<<blocks, 512>>>(d, dc, iters);
@@ -316,6 +367,7 @@ int main() {
     run<11>("i8 16x16x64, 8x4 block", 64, 32768, d, dc);
     run<12>("bf16 32x32x16, 4x2 block", 16, 32768, d, dc);
     run<13>("bf16 16x16x32, 8x4 block", 64, 16384, d, dc);
+    run<40>("bf16 16x16x16 (K = 16 form), 8x4 block", 64, 8192, d, dc);
     run<30>("f16 16x16x32 (asm), accumulators in VGPRs", 64, 16384, d, dc);
     run<31>("f16 16x16x32 (asm), accumulators in AGPRs", 64, 16384, d, dc);
     run<20>("f32 32x32x2, 2x4 block", 32, 4096, d, dc);
