@@ -303,3 +303,37 @@ def test_f32_rows_of_c_longer_than_the_32_bit_reach_of_the_interior_write_back()
         assert float((c[100, ::65537].double() - (a[100].double() @ b[:, ::65537].double())).abs().max() / 1e3) < 1e-5
         del c
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("dtype,ops,size,floor_tops,kernel", [
+    ("float", ("Multiply", "Add"), 16384, 0.92 * 157.3, "mfma_f32_128x256x16_w4x2_flush4096"),   # measured 151.4-152.6 across boxes
+    ("double", ("Multiply", "Add"), 16384, 0.92 * 78.6, "mfma_f64_256x128x16_w8"),               # measured 75.7-76.4
+    ("half", ("Multiply", "Add"), 32768, 1300.0, "mfma_f16_256x256_pingpong_16x16x32"),          # measured 1.44-1.51 PF (power-limited: box-dependent)
+    ("float", ("Add", "Min"), 8192, 0.80 * 78.6, "valu_tile"),                                   # measured 65-75 TOp/s (cold / warm box)
+], ids=lambda v: str(v) if not isinstance(v, tuple) else "_".join(v))
+def test_throughput_floor_of_the_baseline_workloads(dtype, ops, size, floor_tops, kernel):
+    """A regression guard, not a benchmark: the kernels BASELINE.json's configs dispatch must stay within reach of
+    their measured rates (floors ~8-15 % below the slowest box seen), timed by HIP events through mm_gemm_launch after
+    two warm-up launches, best of five."""
+    import ctypes
+    L = g.lib()
+    cfg = g.make_config(dtype, *ops)
+    assert g.kernel_name(cfg, size, size, size) == kernel
+    es = L.mm_dtype_size(g.DTYPES[dtype])
+    ptrs = [ctypes.c_void_p() for _ in range(3)]
+    try:
+        for p in ptrs:
+            g._check(L.mm_alloc(0, size * size * es, ctypes.byref(p)))
+        g._check(L.mm_fill_device(0, g.DTYPES[dtype], ptrs[0], size * size, 11))
+        g._check(L.mm_fill_device(0, g.DTYPES[dtype], ptrs[1], size * size, 12))
+        t, best = ctypes.c_double(0), 1e30
+        for i in range(7):
+            g._check(L.mm_gemm_launch(0, ctypes.byref(cfg), ptrs[0], ptrs[1], ptrs[2], size, size, size, ctypes.byref(t)))
+            if i >= 2:
+                best = min(best, t.value)
+    finally:
+        for p in ptrs:
+            if p.value:
+                L.mm_free(0, p)
+    tops = 2.0 * size ** 3 / best / 1e12
+    assert tops >= floor_tops, f"{kernel}: {tops:.1f} TOp/s, floor {floor_tops:.1f}"
