@@ -308,12 +308,12 @@ def test_f32_rows_of_c_longer_than_the_32_bit_reach_of_the_interior_write_back()
 @pytest.mark.parametrize("dtype,ops,size,floor_tops,kernel", [
     ("float", ("Multiply", "Add"), 16384, 0.92 * 157.3, "mfma_f32_128x256x16_w4x2_flush4096"),   # measured 151.4-152.6 across boxes
     ("double", ("Multiply", "Add"), 16384, 0.92 * 78.6, "mfma_f64_256x128x16_w8"),               # measured 75.7-76.4
-    ("half", ("Multiply", "Add"), 32768, 1300.0, "mfma_f16_256x256_pingpong_16x16x32"),          # measured 1.44-1.51 PF (power-limited: box-dependent)
-    ("float", ("Add", "Min"), 8192, 0.80 * 78.6, "valu_tile"),                                   # measured 65-75 TOp/s (cold / warm box)
+    ("half", ("Multiply", "Add"), 32768, 1250.0, "mfma_f16_256x256_pingpong_16x16x32"),          # measured 1.44-1.51 PF (power-limited: box-dependent)
+    ("float", ("Add", "Min"), 8192, 0.75 * 78.6, "valu_tile"),                                   # measured 65-75 TOp/s (cold / warm box)
 ], ids=lambda v: str(v) if not isinstance(v, tuple) else "_".join(v))
 def test_throughput_floor_of_the_baseline_workloads(dtype, ops, size, floor_tops, kernel):
     """A regression guard, not a benchmark: the kernels BASELINE.json's configs dispatch must stay within reach of
-    their measured rates (floors ~8-15 % below the slowest box seen), timed by HIP events through mm_gemm_launch after
+    their measured rates (floors 5-15 % below the slowest box seen), timed by HIP events through mm_gemm_launch after
     two warm-up launches, best of five."""
     import ctypes
     L = g.lib()
