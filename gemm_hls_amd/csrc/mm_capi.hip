@@ -505,7 +505,14 @@ static int mm_run_host_pointers(const mm_config_t &cfg, const void *a, const voi
   MM_HIP_HP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
   MM_HIP_HP(hipMemcpy(bd, b, (size_t)k * m * es, hipMemcpyHostToDevice));
   // a K x N A is not row-sliceable; small problems are not worth slicing
-  const bool pipelined = cfg.layout_a == MM_A_ROW_MAJOR && (double)n * k * m >= 64.0 * 1024 * 1024 * 1024 && n >= 2048;
+  bool pipelined = cfg.layout_a == MM_A_ROW_MAJOR && (double)n * k * m >= 64.0 * 1024 * 1024 * 1024 && n >= 2048;
+  if (pipelined) {   // a job that one launch would run as stream-K stays one launch: slabs could not reproduce its unit ranges
+    const mm::Problem whole{nullptr, nullptr, nullptr, n, k, m, false};
+    if (choose(cfg, whole) == FAM_MFMA_F32) {
+      const int v = f32_variant_for(whole);
+      if (v >= 0 && mm::mfma_f32_splitk(whole, v) == 0) pipelined = false;
+    }
+  }
   const unsigned slabs = pipelined ? 8 : 1;
   const unsigned slab_rows = ((n + slabs - 1) / slabs + 255) / 256 * 256;
   for (unsigned r0 = 0; r0 < n; r0 += slab_rows) {
@@ -514,7 +521,7 @@ static int mm_run_host_pointers(const mm_config_t &cfg, const void *a, const voi
     char *a_dst = (char *)ad + (cfg.layout_a == MM_A_ROW_MAJOR ? (size_t)r0 * k * es : 0);
     MM_HIP_HP(hipMemcpy(a_dst, a_src, (size_t)(slabs == 1 ? n : rows) * k * es, hipMemcpyHostToDevice));
     mm::Problem p{a_dst, bd, (char *)cd + (size_t)r0 * m * es, slabs == 1 ? n : rows, k, m,
-                  cfg.layout_a == MM_A_TRANSPOSED, n};   // a row slab of the n-row job
+                  cfg.layout_a == MM_A_TRANSPOSED, slabs == 1 ? 0u : n};   // a row slab of the n-row job (or all of it)
     rc = dispatch(stream, cfg, p);
     if (rc) { cleanup(); return rc; }
     hipEvent_t e;
@@ -570,6 +577,7 @@ const char *mm_kernel_name(const mm_config_t *cfg, unsigned n, unsigned k, unsig
                                                 "mfma_f32_128x128x32_w4x2_splitk8"};
       const int splits = mm::mfma_f32_splitk(p, v);
       if (splits == 0) return "mfma_f32_128x128x32_w4x2_streamk";
+      if (splits == 9) return "mfma_f32_128x128x32_w4x2_streamk_fixup";
       return splits > 1 ? split_names[splits] : mm::mfma_f32_name(v);
     }
     case FAM_MFMA_F64: return mm::mfma_f64_name(p);

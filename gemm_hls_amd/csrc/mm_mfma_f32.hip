@@ -599,6 +599,122 @@ __global__ __launch_bounds__(G::THREADS, G::MIN_WAVES) void mfma_f32_streamk_ker
   }
 }
 
+// Stream-K with the combine inside the launch ("ordered hand-over": what f32_splitk = 0 and the shape-adaptive rule run; 9 = the fix-up kernel above, kept as its cross-check).  Same unit ranges.  Observation: every
+// segment of a tile other than its lowest-k one is the FIRST segment of the workgroup that owns it (a range enters a tile
+// from below only at its own start), and the lowest-k segment is the LAST thing its owner does.  So: the others write
+// their scratch slot and raise a flag right away; the owner of the lowest-k segment writes its sum to C, waits for those
+// flags (raised by first segments, normally long ago) and adds the slots on top in ascending k -- C = own + slot + slot ...
+// A fixed order, no atomics on data, no second kernel and half the scratch.  Waits point at higher workgroup ids only,
+// are the last thing a workgroup does and never aim at a segment that itself waits, so the launch makes progress
+// whatever the residency (workgroups are dispatched in id order within an XCD; w + 1 is blockIdx + 8 or XCD x+1's first).  Visibility: the producer's stores, __syncthreads, one lane's agent-scope
+// release + s_waitcnt vmcnt(0) + relaxed agent store of the flag; the consumer's relaxed poll by one lane, agent-scope
+// acquire, __syncthreads, plain loads (MI355X_MICROARCH.md, inter-workgroup visibility: the valid forms).
+//
+// Teams.  With one range per workgroup, neighbouring workgroups sit at different k offsets of neighbouring tiles, so no two
+// of them ever want the same A or B slab at the same time: the XCD's L2 shares nothing and the launch becomes fabric-bound
+// (3968^3: 3.9 GB fetched against 0.93 GB for whole tiles, 133 TF; 4096^3, where the ranges happen to be whole tiles: 0.80
+// GB, 146 TF -- profiles/r03w).  So the ranges go to TEAMS of sr x sc workgroups inside one XCD: the tile grid is cut into
+// super-tiles of sr x sc tiles, a team walks its range of (super-tile, slab) units with workgroup `lane` of the team on
+// tile `lane` of the super-tile, and all of a team are at the same slab at the same time -- each A slab is wanted by sc
+// of them and each B slab by sr.  Per lane this is exactly the scheme above with `teams` ranges.  Tiles of a ragged
+// super-tile that fall outside the matrix are skipped by their lane (the same lane in every team, so no flag is missed).
+template <typename G>
+__global__ __launch_bounds__(G::THREADS, G::MIN_WAVES) void mfma_f32_streamk_ordered_kernel(
+    const float *__restrict__ A, const float *__restrict__ B, float *__restrict__ C, unsigned N, unsigned K, unsigned M,
+    unsigned tiles_n, unsigned tiles_m, unsigned spt, unsigned sr, unsigned sc, unsigned teams_per_xcd, unsigned teams,
+    float *__restrict__ slots, unsigned *__restrict__ flags) {
+  const unsigned lanes = sr * sc, xcd = blockIdx.x % 8, place = blockIdx.x / 8;
+  const unsigned team_in_xcd = place / lanes, lane = place % lanes;
+  const unsigned team = xcd * teams_per_xcd + team_in_xcd, w = team * lanes + lane;
+  if (team_in_xcd >= teams_per_xcd || team >= teams) return;     // teams = min(8 x teams_per_xcd, units): no empty range
+  const unsigned st_rows = (tiles_n + sr - 1) / sr, st_cols = (tiles_m + sc - 1) / sc;
+  const unsigned long long units = (unsigned long long)st_rows * st_cols * spt;   // per lane; teams <= units
+  const unsigned u0 = sk_range_begin(units, team, teams), u1 = sk_range_begin(units, team + 1, teams);
+  for (unsigned u = u0; u < u1;) {
+    const unsigned st = u / spt, s0 = u - st * spt, s1 = min(spt, s0 + (u1 - u));
+    const unsigned tile_r = (st % st_rows) * sr + lane % sr, tile_c = (st / st_rows) * sc + lane / sr;
+    u += s1 - s0;
+    if (tile_r >= tiles_n || tile_c >= tiles_m) continue;        // uniform over the workgroup
+    const unsigned row0 = tile_r * G::BM, col0 = tile_c * G::BN;
+    const unsigned kbeg = s0 * G::BK, klen = (s1 - s0) * G::BK;
+    const float *a = A + kbeg, *b = B + (size_t)kbeg * M;
+    if (s0 == 0 && s1 == spt) {
+      tile_body<G, false>(a, b, C, N, klen, M, K, M, N, M, row0, col0);
+    } else if (s0 > 0) {   // not the lowest-k segment: this workgroup's first segment -> its slot, then the flag
+      float *slot = slots + (size_t)w * (G::BM * G::BN);
+      float *base = (float *)((unsigned long long)slot - ((unsigned long long)row0 * G::BN + col0) * sizeof(float));
+      tile_body<G, false>(a, b, base, N, klen, M, K, G::BN, ~0u, ~0u, row0, col0);
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(flags + w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    } else {               // the lowest-k segment of a split tile: this one into C, then the others on top in ascending k
+      tile_body<G, false>(a, b, C, N, klen, M, K, M, N, M, row0, col0);
+      const unsigned u_hi = st * spt + spt;
+      unsigned t_end = team + 1;
+      while (t_end < teams && sk_range_begin(units, t_end, teams) < u_hi) ++t_end;   // ranges are never empty: teams <= units
+      if (threadIdx.x == 0) {
+        for (unsigned o = team + 1; o < t_end; ++o)
+          while (__hip_atomic_load(flags + o * lanes + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(8);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      }
+      __syncthreads();     // also: this workgroup's own stores to C are visible to all of its wavefronts
+      constexpr int QUADS = G::BM * G::BN / 4 / G::THREADS;
+#pragma unroll 2
+      for (int i = 0; i < QUADS; ++i) {
+        const unsigned q = i * G::THREADS + threadIdx.x, row = row0 + q / (G::BN / 4), col = col0 + (q % (G::BN / 4)) * 4;
+        if (row < N && col < M) {
+          f32x4 *out = (f32x4 *)(C + (size_t)row * M + col);
+          f32x4 acc = *out;
+          for (unsigned o = team + 1; o < t_end; ++o) acc += ((const f32x4 *)(slots + (size_t)(o * lanes + lane) * (G::BM * G::BN)))[q];
+          *out = acc;
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// Team shape for a tile grid: 4, 2 or 1 tiles a side, the largest that divides the grid exactly -- a ragged super-tile idles
+// its outside lanes for whole segments and costs more than the sharing returns (profiles/r03w_f32_streamk_teams.txt: 2816^3,
+// 22 x 22 tiles, 4 x 4 teams 113 TF against 128; 3584^3, 28 x 28, 140 against 137; 5120^3 146 against 142).  Wider teams
+// (8 x 4, 8 x 8) measured no better than 4 x 4 where they divide.
+struct TeamShape { unsigned sr, sc; };
+static TeamShape streamk_team_shape(unsigned tiles_n, unsigned tiles_m) {
+  auto side = [](unsigned t) { return t % 4 == 0 ? 4u : t % 2 == 0 ? 2u : 1u; };
+  return {side(tiles_n), side(tiles_m)};
+}
+
+template <typename G>
+int launch_streamk_ordered(hipStream_t s, const Problem &p) {
+  const unsigned tiles_n = (p.n + G::BM - 1) / G::BM, tiles_m = (p.m + G::BN - 1) / G::BN, spt = p.k / G::BK;
+  const TeamShape ts = streamk_team_shape(tiles_n, tiles_m);
+  const unsigned nwg = 512, teams_per_xcd = 64 / (ts.sr * ts.sc);   // 8 XCDs x 64 places
+  const unsigned long long units = (unsigned long long)(tiles_n / ts.sr) * (tiles_m / ts.sc) * spt;
+  const unsigned teams = (unsigned)std::min<unsigned long long>(8 * teams_per_xcd, units);
+  static_assert(G::MIN_WAVES == 2, "two workgroups per CU: 64 places per XCD");
+  static unsigned long long configured = 0;
+  if (int e = ensure_dynamic_lds((const void *)mfma_f32_streamk_ordered_kernel<G>, G::LDS_BYTES, configured)) return e;
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return (int)e;
+  hipMemPool_t pool = nullptr;
+  if (int rc = workspace_pool(dev, &pool)) return rc;
+  const size_t slot_bytes = (size_t)nwg * G::BM * G::BN * sizeof(float);
+  char *ws = nullptr;
+  if ((e = hipMallocFromPoolAsync((void **)&ws, slot_bytes + nwg * sizeof(unsigned), pool, s)) != hipSuccess) return (int)e;
+  if ((e = hipMemsetAsync(ws + slot_bytes, 0, nwg * sizeof(unsigned), s)) != hipSuccess) { (void)hipFreeAsync(ws, s); return (int)e; }
+  (void)hipGetLastError();
+  hipLaunchKernelGGL((mfma_f32_streamk_ordered_kernel<G>), dim3(nwg), dim3(G::THREADS), G::LDS_BYTES, s, (const float *)p.a,
+                     (const float *)p.b, (float *)p.c, p.n, p.k, p.m, tiles_n, tiles_m, spt, ts.sr, ts.sc, teams_per_xcd, teams,
+                     (float *)ws, (unsigned *)(ws + slot_bytes));
+  const int rc = (int)hipGetLastError();
+  const hipError_t f = hipFreeAsync(ws, s);
+  return rc ? rc : (int)f;
+}
+
 // C tile = sum of the scratch slots of the workgroups whose ranges cut it, ascending k.  One workgroup per tile; tiles that
 // one range covered whole were written by the main kernel and are skipped.
 template <int BM, int BN>
@@ -749,22 +865,22 @@ int mfma_f32_variant_id(int index) { return index >= 0 && index < mfma_f32_num_v
 // relative efficiency.
 static const TileCandidate kAutoCands[] = {{33, 128, 256, 2, 1.00}, {8, 256, 256, 1, 0.991}, {35, 128, 128, 2, 0.993}};
 
-// Stream-K (launch_streamk) against the best whole-tile launch, in pick_tile's units (tile area x workgroups the busiest CU
-// runs one after the other).  Fitted to profiles/r03q_f32_streamk_mid_sizes.txt: the persistent workgroups run 8 % below
-// the whole-tile kernel (segment prologues and epilogues), every split tile costs a scratch write, a read and a share of
-// the fix-up kernel (at most one split tile per workgroup boundary), plus a second launch.  It pays where the last round
-// of whole tiles would leave much of the chip idle -- 2304^3 +28 %, 3072^3 +22 %, 3584^3 +17 %, 2560^3 +9 % -- and is not
-// taken where whole tiles fit (2048^3, 2816^3, 4096^3, 6144^3) nor below a full round's worth of tiles per two CUs
-// (<= 256 tiles: split-K or the plain kernel, see mfma_f32_splitk).  Jobs of more than two rounds of tiles always run whole
-// tiles, which is also what keeps the row slabs of the host-pointer pipeline and of the N-split over GPUs bit-identical to
-// the one-launch result for everything of BASELINE's size.
+// Stream-K (launch_streamk_ordered) against the best whole-tile launch, in pick_tile's units (tile area x workgroups the
+// busiest CU runs one after the other; a full round of 512 tiles of 128 x 128 = 2).  Fitted to
+// profiles/r03w_f32_streamk_ordered_sweep.txt (2176^3 ... 8192^3 in steps of 128 / 256): the persistent workgroups run at
+// the whole-tile kernel's rate, plus 0.3 of a tile for the launch's one-off parts that whole tiles of a multi-round launch
+// hide behind each other -- the cold first slabs, the scratch write and gather of the cut tiles, all C written at the same
+// moment.  It pays where the last round of whole tiles would leave much of the chip idle: 2304^3 +30 %, 2944^3 +30 %,
+// 3072^3 +24 %, 3584^3 +22 %, 5120^3 +10 %, 4608^3 +7 %; it is not taken where whole tiles fit (2816^3, 3456^3, 4096^3,
+// 5376^3, 6144^3), below a full round's worth of tiles per two CUs (<= 256 tiles: split-K or the plain kernel, see
+// mfma_f32_splitk) or above four rounds (> 2048 tiles: whole tiles are within 2 % or ahead from there on).
 static bool streamk_wins(const Problem &p) {
   if (p.a_transposed || p.k % 32 != 0 || p.k < 256 || p.n_total) return false;
   const double tiles = (double)((p.n + 127) / 128) * ((p.m + 127) / 128);
-  if (tiles <= 256 || tiles > 1024) return false;   // from two full rounds on, whole tiles lose at most a few % (5120^3: 4 %)
+  if (tiles <= 256 || tiles > 2048) return false;
   double whole = 0;
   pick_tile(kAutoCands, 3, p.n, p.m, &whole);
-  const double sk = (2.16 * tiles / 512 + 0.24 * (tiles < 512 ? tiles : 512) / 512 + 0.04) * 128 * 128 / 0.993;
+  const double sk = (2.0 * tiles / 512 + 0.30) * 128 * 128 / 0.993;
   return sk < 0.97 * whole;
 }
 
@@ -796,13 +912,13 @@ int mfma_f32_resolve(const Problem &p, int variant) {
 // leave a quarter or more of the CUs without a workgroup (<= 192 tiles), K is cut into S = min(slots / tiles, K / 256, 8) chunks, the S copies of the tile grid run
 // side by side and a second kernel adds the S partial planes in ascending order -- deterministic, run to run and
 // whatever the placement, but a different summation order than the unsplit kernel (as accurate or better: shorter
-// chains).  f32_splitk: -1 this rule (and stream-K by streamk_wins), 0 stream-K, 1 neither, 2..8 that many chunks (always only
+// chains).  f32_splitk: -1 this rule (and stream-K by streamk_wins), 0 stream-K, 1 neither, 2..8 that many chunks, 9 stream-K with the fix-up kernel (always only
 // for row-major A and variant 35).  Row slabs of a bigger job (Problem::n_total) never take stream-K: its unit ranges would
 // depend on the slab, and with them a row's summation order.
 int mfma_f32_splitk(const Problem &p, int variant) {
   if (p.a_transposed || variant != 35) return 1;
   const int knob = tuning(TUNE_F32_SPLITK);
-  if (knob == 0) return (p.k % 32 == 0 && p.k >= 64) ? 0 : 1;   // 0 = stream-K (forced by the knob; see launch_streamk)
+  if (knob == 0 || knob == 9) return (p.k % 32 == 0 && p.k >= 64) ? knob : 1;   // stream-K forced: 0 = ordered hand-over (the one auto takes), 9 = fix-up kernel
   const unsigned rows = p.n_total ? p.n_total : p.n;   // of the whole job (Problem::n_total)
   const unsigned long long tiles = (unsigned long long)((rows + 127) / 128) * ((p.m + 127) / 128);
   unsigned s;
@@ -842,7 +958,8 @@ int launch_mfma_f32(hipStream_t s, const Problem &p, int variant) {
     case 8: return sdma_fits(p, 16) ? launch_geo<T256x256>(s, p) : launch_geo<T256x256v>(s, p);
     case 35: {
       const int splits = mfma_f32_splitk(p, v);
-      if (splits == 0) return sdma_fits(p, 32) ? launch_streamk<T128x128>(s, p) : launch_streamk<T128x128v>(s, p);
+      if (splits == 0) return sdma_fits(p, 32) ? launch_streamk_ordered<T128x128>(s, p) : launch_streamk_ordered<T128x128v>(s, p);
+      if (splits == 9) return sdma_fits(p, 32) ? launch_streamk<T128x128>(s, p) : launch_streamk<T128x128v>(s, p);
       return sdma_fits(p, 32) ? launch_geo<T128x128>(s, p, (unsigned)splits) : launch_geo<T128x128v>(s, p, (unsigned)splits);
     }
     case 0: return launch_geo<X128x256x32_2lvl>(s, p);

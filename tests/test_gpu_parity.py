@@ -120,13 +120,17 @@ def test_f32_split_k_for_small_problems_is_deterministic_and_accurate(shape, spl
 
 
 @pytest.mark.parametrize("shape,forced", [((2304, 2304, 2304), False), ((3072, 1056, 520), True), ((1000, 96, 3000), True),
-                                          ((2560, 512, 2560), False), ((129, 4096, 132), True), ((3584, 256, 3584), False), ((100, 96, 120), True), ((300, 64, 272), True)],
+                                          ((2560, 512, 2560), False), ((129, 4096, 132), True), ((3584, 256, 3584), False), ((100, 96, 120), True), ((300, 64, 272), True),
+                                          ((5120, 256, 5120), False), ((2341, 2304, 2304), True), ((128, 32768, 128), True), ((2432, 288, 3712), False)],
                          ids=lambda v: "x".join(map(str, v)) if isinstance(v, tuple) else ("forced" if v else "auto"))
 def test_f32_stream_k_for_partial_rounds_is_deterministic_and_accurate(shape, forced):
     """Round 3: problems of a few partial rounds of 128 x 128 tiles are dealt out to 512 persistent workgroups in equal
-    ranges of (tile, slab) units; tiles cut by a range boundary go through scratch slots and are added in ascending k by
-    a second kernel.  Same bits on every launch; inside the fp32 bound; picked by the shape-adaptive rule where it pays
-    (`auto` cases) and forcible through f32_splitk = 0 (ragged N / M, K of 3 slabs, ranges shorter than a tile)."""
+    ranges of (tile, slab) units -- to teams of up to 4 x 4 workgroups on neighbouring tiles, so that an XCD's L2 still shares
+    the slabs.  A tile cut by a range boundary is finished inside the launch: the other parts go to scratch slots and raise a
+    flag, the owner of the lowest-k part writes C and adds the slots on top in ascending k.  Same bits on every launch;
+    inside the fp32 bound; picked by the shape-adaptive rule where it pays (`auto` cases) and forcible through
+    f32_splitk = 0 (ragged N / M, K of 3 slabs, ranges shorter than a tile, one tile cut 512 ways).  f32_splitk = 9 is
+    the two-kernel form (slots for every part, a fix-up kernel adds them): an independent implementation of the same idea."""
     n, k, m = shape
     rng = np.random.default_rng(k + n)
     a = rng.uniform(-3, 10, size=(n, k)).astype(np.float32)
@@ -138,18 +142,24 @@ def test_f32_stream_k_for_partial_rounds_is_deterministic_and_accurate(shape, fo
             g.set_tuning("f32_variant", 35)
             g.set_tuning("f32_splitk", 0)
         name = g.kernel_name(g.make_config("float"), n, k, m)
-        c1, _ = g.matmul_capi(a, b)
-        c2, _ = g.matmul_capi(a, b)
+        runs = [g.matmul_capi(a, b)[0] for _ in range(3)]
         g.set_tuning("f32_variant", 35)
+        g.set_tuning("f32_splitk", 9)
+        name_fixup = g.kernel_name(g.make_config("float"), n, k, m)
+        c_fixup, _ = g.matmul_capi(a, b)
         g.set_tuning("f32_splitk", 1)
         c_one, _ = g.matmul_capi(a, b)
     finally:
         g.set_tuning("f32_splitk", -1)
         g.set_tuning("f32_variant", -1)
     assert name == "mfma_f32_128x128x32_w4x2_streamk", name
-    assert np.array_equal(c1, c2)
+    assert name_fixup == "mfma_f32_128x128x32_w4x2_streamk_fixup", name_fixup
+    c1 = runs[0]
+    assert np.array_equal(c1, runs[1]) and np.array_equal(c1, runs[2])
     assert np.max(np.abs(c1 - exact) / scale) < 2e-6
+    assert np.max(np.abs(c_fixup - exact) / scale) < 2e-6
     assert np.max(np.abs(c1 - c_one) / scale) < 5e-6
+    assert np.max(np.abs(c1 - c_fixup) / scale) < 5e-6
 
 
 @pytest.mark.parametrize("shape", [(516, 528, 528), (4, 16, 16), (300, 64, 272), (1024, 4112, 512), (260, 8, 4)],

@@ -326,3 +326,85 @@ def test_streamk_ranges_random_configurations():
         for tile in rnd.sample(sorted(split), min(20, len(split))):
             keys = _streamk_fixup(tile, tiles, spt, nwg)
             assert keys == [k for _, _, k in sorted((s0, s1, k) for k, (t, s0, s1) in slots.items() if t == tile)]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Stream-K with the ordered hand-over inside the launch (mfma_f32_streamk_ordered_kernel / launch_streamk_ordered), replayed
+# with the kernel's integer formulas: teams of sr x sc workgroups walk equal ranges of (super-tile, slab) units; a segment
+# that does not begin a tile is its workgroup's FIRST one (-> slot + flag), a segment that begins a tile but does not end it
+# is its workgroup's LAST one (-> C, then waits for and adds the slots of the following teams' same lane).  Checked: every
+# (tile, slab) multiplied once; the gather of a cut tile adds exactly the slots written for it, in ascending k; every wait
+# aims at a flag that is raised by a segment which itself never waits (no cycle), and no slot is written twice.
+def _team_side(t):
+    return 4 if t % 4 == 0 else 2 if t % 2 == 0 else 1
+
+
+def _ordered_replay(tiles_n, tiles_m, spt):
+    sr, sc = _team_side(tiles_n), _team_side(tiles_m)
+    lanes, tpx = sr * sc, 64 // (sr * sc)
+    st_rows, st_cols = -(-tiles_n // sr), -(-tiles_m // sc)
+    units = st_rows * st_cols * spt
+    teams = min(8 * tpx, units)
+    covered, slot_of, waits, whole, lowest = {}, {}, [], set(), {}
+    for block in range(512):
+        xcd, place = block % 8, block // 8
+        team_in_xcd, lane = place // lanes, place % lanes
+        team = xcd * tpx + team_in_xcd
+        if team_in_xcd >= tpx or team >= teams:
+            continue
+        w = team * lanes + lane
+        u0, u1 = _sk_begin(units, team, teams), _sk_begin(units, team + 1, teams)
+        assert u1 > u0
+        u, index = u0, 0
+        segments = []
+        while u < u1:
+            st = u // spt
+            s0 = u - st * spt
+            s1 = min(spt, s0 + (u1 - u))
+            u += s1 - s0
+            tile = ((st % st_rows) * sr + lane % sr, (st // st_rows) * sc + lane // sr)
+            assert tile[0] < tiles_n and tile[1] < tiles_m          # the team shape divides the grid
+            segments.append((tile, s0, s1))
+        for index, (tile, s0, s1) in enumerate(segments):
+            for sl in range(s0, s1):
+                assert (tile, sl) not in covered
+                covered[(tile, sl)] = w
+            if s0 == 0 and s1 == spt:
+                whole.add(tile)
+            elif s0 > 0:
+                assert index == 0 and w not in slot_of              # first segment; one slot per workgroup
+                slot_of[w] = (tile, s0, s1)
+            else:
+                assert index == len(segments) - 1                   # the waiting segment is the last thing it does
+                st = (tile[0] // sr) + (tile[1] // sc) * st_rows
+                u_hi = st * spt + spt
+                t_end = team + 1
+                while t_end < teams and _sk_begin(units, t_end, teams) < u_hi:
+                    t_end += 1
+                lowest[tile] = (s1, [o * lanes + lane for o in range(team + 1, t_end)])
+    assert len(covered) == tiles_n * tiles_m * spt
+    for tile, (s1, sources) in lowest.items():
+        assert sources, "a cut tile with nothing to gather"
+        k = s1
+        for o in sources:                                           # ascending k, contiguous, each one really written for this tile
+            t, a, b = slot_of[o]
+            assert t == tile and a == k
+            k = b
+        assert k == spt
+    cut = {t for (t, _, _) in slot_of.values()}
+    assert cut == set(lowest) and not (cut & whole) and len(cut | whole) == tiles_n * tiles_m
+    return sr, sc, teams
+
+
+@pytest.mark.parametrize("tiles_n,tiles_m,spt", [(18, 18, 72), (20, 20, 80), (24, 24, 96), (28, 28, 8), (31, 31, 124), (40, 40, 160), (1, 1, 3),
+                                                 (1, 1, 1024), (8, 8, 32), (3, 24, 33), (19, 18, 72), (32, 32, 128), (2, 2, 2), (24, 5, 9), (4, 4, 1)])
+def test_streamk_ordered_hand_over_replayed(tiles_n, tiles_m, spt):
+    sr, sc, teams = _ordered_replay(tiles_n, tiles_m, spt)
+    assert tiles_n % sr == 0 and tiles_m % sc == 0 and 1 <= teams <= 512
+
+
+def test_streamk_ordered_hand_over_random_grids():
+    import random
+    rnd = random.Random(11)
+    for _ in range(150):
+        _ordered_replay(rnd.randint(1, 45), rnd.randint(1, 45), rnd.randint(1, 160))
