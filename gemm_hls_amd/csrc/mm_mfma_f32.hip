@@ -625,8 +625,8 @@ __global__ __launch_bounds__(G::THREADS, G::MIN_WAVES) void mfma_f32_streamk_ord
     float *__restrict__ slots, unsigned *__restrict__ flags) {
   const unsigned lanes = sr * sc, xcd = blockIdx.x % 8, place = blockIdx.x / 8;
   const unsigned team_in_xcd = place / lanes, lane = place % lanes;
-  const unsigned team = xcd * teams_per_xcd + team_in_xcd, w = team * lanes + lane;
-  if (team_in_xcd >= teams_per_xcd || team >= teams) return;     // teams = min(8 x teams_per_xcd, units): no empty range
+  const unsigned team = team_in_xcd * 8 + xcd, w = team * lanes + lane;   // consecutive teams on consecutive XCDs: fewer teams than places still use all eight
+  if (team_in_xcd >= teams_per_xcd || team >= teams) return;     // teams <= 8 x teams_per_xcd, <= units: no empty range
   const unsigned st_rows = (tiles_n + sr - 1) / sr, st_cols = (tiles_m + sc - 1) / sc;
   const unsigned long long units = (unsigned long long)st_rows * st_cols * spt;   // per lane; teams <= units
   const unsigned u0 = sk_range_begin(units, team, teams), u1 = sk_range_begin(units, team + 1, teams);
@@ -661,16 +661,23 @@ __global__ __launch_bounds__(G::THREADS, G::MIN_WAVES) void mfma_f32_streamk_ord
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       }
       __syncthreads();     // also: this workgroup's own stores to C are visible to all of its wavefronts
+      // one slot at a time, all of a thread's quads in flight together: a slot costs one trip to memory, not QUADS of them
       constexpr int QUADS = G::BM * G::BN / 4 / G::THREADS;
-#pragma unroll 2
+      f32x4 acc[QUADS];
+#pragma unroll
       for (int i = 0; i < QUADS; ++i) {
         const unsigned q = i * G::THREADS + threadIdx.x, row = row0 + q / (G::BN / 4), col = col0 + (q % (G::BN / 4)) * 4;
-        if (row < N && col < M) {
-          f32x4 *out = (f32x4 *)(C + (size_t)row * M + col);
-          f32x4 acc = *out;
-          for (unsigned o = team + 1; o < t_end; ++o) acc += ((const f32x4 *)(slots + (size_t)(o * lanes + lane) * (G::BM * G::BN)))[q];
-          *out = acc;
-        }
+        acc[i] = (row < N && col < M) ? *(const f32x4 *)(C + (size_t)row * M + col) : (f32x4)0.0f;
+      }
+      for (unsigned o = team + 1; o < t_end; ++o) {
+        const f32x4 *src = (const f32x4 *)(slots + (size_t)(o * lanes + lane) * (G::BM * G::BN));
+#pragma unroll
+        for (int i = 0; i < QUADS; ++i) acc[i] += src[i * G::THREADS + threadIdx.x];
+      }
+#pragma unroll
+      for (int i = 0; i < QUADS; ++i) {
+        const unsigned q = i * G::THREADS + threadIdx.x, row = row0 + q / (G::BN / 4), col = col0 + (q % (G::BN / 4)) * 4;
+        if (row < N && col < M) *(f32x4 *)(C + (size_t)row * M + col) = acc[i];
       }
     }
     __syncthreads();
@@ -692,8 +699,12 @@ int launch_streamk_ordered(hipStream_t s, const Problem &p) {
   const unsigned tiles_n = (p.n + G::BM - 1) / G::BM, tiles_m = (p.m + G::BN - 1) / G::BN, spt = p.k / G::BK;
   const TeamShape ts = streamk_team_shape(tiles_n, tiles_m);
   const unsigned nwg = 512, teams_per_xcd = 64 / (ts.sr * ts.sc);   // 8 XCDs x 64 places
-  const unsigned long long units = (unsigned long long)(tiles_n / ts.sr) * (tiles_m / ts.sc) * spt;
-  const unsigned teams = (unsigned)std::min<unsigned long long>(8 * teams_per_xcd, units);
+  const unsigned long long super_tiles = (unsigned long long)(tiles_n / ts.sr) * (tiles_m / ts.sc), units = super_tiles * spt;
+  // every place gets a team when there is work for it: a team's range is at least 8 slabs (below that the fill and drain
+  // of the rings outweigh the slabs -- the chunk floor of split-K) and a tile is cut at most 8 ways (the gather is serial
+  // in the owner of the lowest part, and a wait never aims further than 8 teams ahead -- with workgroups dispatched in id
+  // order a launch therefore keeps moving on whatever share of the chip it gets next to other kernels)
+  const unsigned teams = (unsigned)std::max<unsigned long long>(1, std::min<unsigned long long>({8ull * teams_per_xcd, units / 8, 8 * super_tiles}));
   static_assert(G::MIN_WAVES == 2, "two workgroups per CU: 64 places per XCD");
   static unsigned long long configured = 0;
   if (int e = ensure_dynamic_lds((const void *)mfma_f32_streamk_ordered_kernel<G>, G::LDS_BYTES, configured)) return e;
@@ -867,21 +878,23 @@ static const TileCandidate kAutoCands[] = {{33, 128, 256, 2, 1.00}, {8, 256, 256
 
 // Stream-K (launch_streamk_ordered) against the best whole-tile launch, in pick_tile's units (tile area x workgroups the
 // busiest CU runs one after the other; a full round of 512 tiles of 128 x 128 = 2).  Fitted to
-// profiles/r03w_f32_streamk_ordered_sweep.txt (2176^3 ... 8192^3 in steps of 128 / 256): the persistent workgroups run at
-// the whole-tile kernel's rate, plus 0.3 of a tile for the launch's one-off parts that whole tiles of a multi-round launch
-// hide behind each other -- the cold first slabs, the scratch write and gather of the cut tiles, all C written at the same
+// profiles/r03w_f32_streamk_ordered_sweep.txt (2176^3 ... 9216^3): the persistent workgroups run at the whole-tile
+// kernel's rate, plus a quarter of a tile for the launch's one-off parts that the whole tiles of a multi-round launch hide
+// behind each other -- the cold first slabs, the scratch write and gather of the cut tiles, all of C written at the same
 // moment.  It pays where the last round of whole tiles would leave much of the chip idle: 2304^3 +30 %, 2944^3 +30 %,
-// 3072^3 +24 %, 3584^3 +22 %, 5120^3 +10 %, 4608^3 +7 %; it is not taken where whole tiles fit (2816^3, 3456^3, 4096^3,
-// 5376^3, 6144^3), below a full round's worth of tiles per two CUs (<= 256 tiles: split-K or the plain kernel, see
-// mfma_f32_splitk) or above four rounds (> 2048 tiles: whole tiles are within 2 % or ahead from there on).
+// 3072^3 +20 %, 3584^3 +23 %, 4608^3 +15 %, 5120^3 +10 %, 5888^3 +6 %, 7680^3 +6 %; it is not taken where whole tiles fit
+// (2816^3, 3456^3, 4096^3, 5376^3, 6144^3, 8192^3) nor below a full round's worth of tiles per two CUs (<= 256 tiles:
+// split-K or the plain kernel, see mfma_f32_splitk).
 static bool streamk_wins(const Problem &p) {
   if (p.a_transposed || p.k % 32 != 0 || p.k < 256 || p.n_total) return false;
   const double tiles = (double)((p.n + 127) / 128) * ((p.m + 127) / 128);
-  if (tiles <= 256 || tiles > 2048) return false;
+  const unsigned tn = (p.n + 127) / 128, tm = (p.m + 127) / 128;
+  const bool teams_4x4 = tn % 4 == 0 && tm % 4 == 0;               // streamk_team_shape: full sharing inside an XCD
+  if (tiles <= 256 || tiles > (teams_4x4 ? 4096 : 2304)) return false;   // smaller teams turn fabric-bound as the job grows (54^2, 58^2, 62^2 tiles: -3 %)
   double whole = 0;
   pick_tile(kAutoCands, 3, p.n, p.m, &whole);
-  const double sk = (2.0 * tiles / 512 + 0.30) * 128 * 128 / 0.993;
-  return sk < 0.97 * whole;
+  const double sk = (2.0 * tiles / 512 + 0.25) * 128 * 128 / 0.993;
+  return sk < 0.99 * whole;
 }
 
 int mfma_f32_auto_variant(const Problem &p) {

@@ -162,6 +162,43 @@ def test_f32_stream_k_for_partial_rounds_is_deterministic_and_accurate(shape, fo
     assert np.max(np.abs(c1 - c_fixup) / scale) < 5e-6
 
 
+def test_f32_stream_k_launches_sharing_the_chip_make_progress_and_keep_their_bits():
+    """The ordered hand-over waits inside the kernel (a workgroup on flags of workgroups with higher ids).  Two such launches
+    on two streams, plus a third stream of whole-tile launches, compete for the same CUs, so neither has all of its
+    workgroups resident: each must still finish (waits only ever aim a bounded distance ahead in dispatch order) and give
+    the bits it gives alone.  Run under a watchdog: a hang here would otherwise take the box down with it."""
+    import torch
+    dev = torch.device("cuda:0")
+    shapes = [(2341, 2304, 2304), (3584, 512, 3584), (2048, 2048, 2048)]
+    ops = []
+    for i, (n, k, m) in enumerate(shapes):
+        a = torch.empty((n, k), device=dev).uniform_(-3, 10, generator=torch.Generator(device=dev).manual_seed(i))
+        b = torch.empty((k, m), device=dev).uniform_(-3, 10, generator=torch.Generator(device=dev).manual_seed(10 + i))
+        ops.append((a, b))
+    names = [g.kernel_name(g.make_config("float"), *sh) for sh in shapes]
+    assert names[0].endswith("streamk") and names[1].endswith("streamk") and "streamk" not in names[2], names
+    alone = [g.matmul(a, b).clone() for a, b in ops]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in shapes]
+    outs = [[] for _ in shapes]
+    for rep in range(25):
+        for i, (a, b) in enumerate(ops):
+            with torch.cuda.stream(streams[i]):
+                outs[i].append(g.matmul(a, b))
+    done = torch.cuda.Event()
+    for st in streams:
+        torch.cuda.current_stream().wait_stream(st)
+    done.record()
+    import time
+    t0 = time.time()
+    while not done.query():
+        assert time.time() - t0 < 60, "stream-K launches sharing the chip did not finish"
+        time.sleep(0.01)
+    for i in range(len(shapes)):
+        for c in outs[i]:
+            assert torch.equal(c, alone[i]), names[i]
+
+
 @pytest.mark.parametrize("shape", [(516, 528, 528), (4, 16, 16), (300, 64, 272), (1024, 4112, 512), (260, 8, 4)],
                          ids=lambda s: "x".join(map(str, s)))
 def test_f32_mfma_transposed_a_layout(shape):

@@ -344,12 +344,12 @@ def _ordered_replay(tiles_n, tiles_m, spt):
     lanes, tpx = sr * sc, 64 // (sr * sc)
     st_rows, st_cols = -(-tiles_n // sr), -(-tiles_m // sc)
     units = st_rows * st_cols * spt
-    teams = min(8 * tpx, units)
+    teams = max(1, min(8 * tpx, units // 8, 8 * st_rows * st_cols))
     covered, slot_of, waits, whole, lowest = {}, {}, [], set(), {}
     for block in range(512):
         xcd, place = block % 8, block // 8
         team_in_xcd, lane = place // lanes, place % lanes
-        team = xcd * tpx + team_in_xcd
+        team = team_in_xcd * 8 + xcd
         if team_in_xcd >= tpx or team >= teams:
             continue
         w = team * lanes + lane
@@ -384,7 +384,7 @@ def _ordered_replay(tiles_n, tiles_m, spt):
                 lowest[tile] = (s1, [o * lanes + lane for o in range(team + 1, t_end)])
     assert len(covered) == tiles_n * tiles_m * spt
     for tile, (s1, sources) in lowest.items():
-        assert sources, "a cut tile with nothing to gather"
+        assert 1 <= len(sources) <= 8, "a cut tile gathers from 1..8 following teams"
         k = s1
         for o in sources:                                           # ascending k, contiguous, each one really written for this tile
             t, a, b = slot_of[o]
