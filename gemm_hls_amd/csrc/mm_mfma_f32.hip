@@ -450,7 +450,9 @@ __device__ __forceinline__ void tile_body(const float *__restrict__ A, const flo
     for (unsigned t0 = 0; t0 < steady; t0 += G::CHUNK) {
       const unsigned tend = min(t0 + (unsigned)G::CHUNK, steady);
       for (unsigned t = t0; t < tend; ++t) slab(t);
-      if (tend < steady) {  // a further chunk follows: C (+)= acc, restart the chain
+      // a further chunk follows: C (+)= acc, restart the chain.  The rule is in k, not in slabs, so that every geometry
+      // flushes at the same points whatever its BK: after each 4096 k that more than 32 k follow (32 = the deepest slab)
+      if (tend < steady && K > tend * BK + 32) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         flush_tile(flushed);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
