@@ -559,6 +559,214 @@ __global__ __launch_bounds__(G::THREADS, G::MIN_WAVES) void mfma_f32_kernel(cons
   tile_body<G, AT>(A, B, C, N, K, M, lda, M, N, M, tile_row * G::BM, tile_col * G::BN);
 }
 
+// ---- small problems (round 3): 64 x 64 tiles, one 32 x 32 accumulator per wavefront -------------------------------------
+// Below a round of 128 x 128 tiles the chip has more SIMDs than the problem has wavefront tiles of 32 x 128 (1024^3: 256 for
+// 1024 SIMDs), which split-K answers with partial planes and a second kernel.  This geometry instead makes the wavefront
+// tile 32 x 32 -- a workgroup of 2 x 2 wavefronts owns 64 x 64 of C, two workgroups per CU (64 KiB of LDS each) --
+// so that 1024^3 is 256 workgroups of whole K and no reduction.  The price: twice the L2 -> LDS bytes per flop of the
+// 128 x 128 tile, and every MFMA of a wavefront accumulates into the same registers (a dependent chain: 94 % of the
+// matrix-core rate with one wavefront per SIMD, 100 % with two -- tools/probes/probe_mfma_chain.hip).
+// Arithmetic: per output element exactly the chain of tile_body -- k-groups of 8 ascending, inside a group the MFMA
+// pairs (p, p + 4), accumulators flushed into C after every 4096 k that more than 32 k follow -- so the result has the
+// bits of the other shipped geometries (tested).  Row-major A only.
+//   A slab in LDS: [64 rows][8 chunks of 4 k], chunk index XOR (row >> 1) & 7 (the 16 lanes of a ds_read_b128 service
+//     group -- 16 rows, one logical chunk -- hit 16 distinct 16-B slots of the 256-B bank row);
+//   B slab in LDS: [32 k][16 chunks of 4 columns], chunk index XOR 8 for k & 4: the MFMA's B operand is one float per
+//     lane, B[k = p + 4 * (lane >> 5)][column lane & 31], read with ds_read_b32 -- lanes 0-31 take 32 consecutive dwords
+//     of k-row p, lanes 32-63 the same columns of k-row p + 4, which the XOR moves to the other 32 banks.
+//   (Both enumerated in tests/test_layouts.py.)  Ring of four stages, one barrier per slab, the order of MFMAs, DMA pieces and
+//   fragment reads pinned (below).
+template <int NS_>
+struct SmallT {
+  static constexpr int BM = 64, BN = 64, BK = 32, NS = NS_, NW = 4, THREADS = 256;
+  static constexpr int A_BYTES = BM * BK * 4, B_BYTES = BK * BN * 4, STAGE_BYTES = A_BYTES + B_BYTES, LDS_BYTES = NS * STAGE_BYTES;
+  static constexpr int PER_CU = 160 * 1024 / LDS_BYTES > 3 ? 3 : 160 * 1024 / LDS_BYTES;
+  static constexpr int CHUNK = 128;   // slabs per link of the chain: 4096 k
+  static constexpr int L = 4;         // DMA instructions per wavefront per slab: 2 of A, 2 of B
+};
+
+using Small = SmallT<4>;
+
+template <typename G>
+__global__ __launch_bounds__(G::THREADS, G::PER_CU) void mfma_f32_small_kernel(
+    const float *__restrict__ A, const float *__restrict__ B, float *__restrict__ C, unsigned N, unsigned K, unsigned M,
+    unsigned tiles_n, unsigned tiles_m, unsigned kBand) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const unsigned nwg = tiles_n * tiles_m;
+  const unsigned lin = xcd_remap(blockIdx.x, nwg);
+  const unsigned band = lin / (kBand * tiles_m), within = lin % (kBand * tiles_m);
+  const unsigned rows_in_band = min(kBand, tiles_n - band * kBand);
+  const unsigned row0 = (band * kBand + within % rows_in_band) * G::BM, col0 = (within / rows_in_band) * G::BN;
+
+  const unsigned lane = threadIdx.x & 63u;
+  const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const unsigned wm = wave >> 1, wn = wave & 1u, lo = lane & 31u, hi = lane >> 5;
+
+  // per-lane DMA sources (clamped: a slab index past the end, a row past N or a column chunk past M fetch valid bytes
+  // that are never multiplied into a stored element)
+  size_t a_row_off[2];
+  unsigned a_k[2], b_k[2], b_col[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const unsigned slot = (wave + 4 * i) * 64 + lane;
+    const unsigned row = slot >> 3, pc = slot & 7u;
+    a_k[i] = (pc ^ ((row >> 1) & 7u)) * 4;
+    a_row_off[i] = (size_t)min(row0 + row, N - 1) * K;
+    const unsigned k = slot >> 4, pcb = slot & 15u;
+    b_k[i] = k;
+    b_col[i] = min(col0 + (pcb ^ ((k & 4u) << 1)) * 4, M - 4);
+  }
+  auto stage = [&](unsigned buf, unsigned k0) {
+    char *base = smem + buf * G::STAGE_BYTES;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)(A + a_row_off[i] + min(k0 + a_k[i], K - 4)), (lptr_t)(base + (wave + 4 * i) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)(B + (size_t)min(k0 + b_k[i], K - 1) * M + b_col[i]),
+                                       (lptr_t)(base + G::A_BYTES + (wave + 4 * i) * 1024), 16, 0, 0);
+  };
+
+  // Steady state (K >= 32): the same pieces with a wavefront-uniform 64-bit base in SGPRs and a constant 32-bit per-lane
+  // offset (global_load_lds_dwordx4 v, s[base:base+1]) -- no address arithmetic on the vector ALU.  A slab start past K - 32
+  // (beyond the end, or the partial last slab) is clamped to K - 32, uniformly: a partial last slab then sits at the END
+  // of its stage (see the last-slab loop).  64 rows x K x 4 B and 32 k-rows x M x 4 B stay below 4 GiB (launcher).
+  unsigned voa[2], vob[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const unsigned slot = (wave + 4 * i) * 64 + lane;
+    voa[i] = (min(row0 + (slot >> 3), N - 1) - row0) * K * 4u + a_k[i] * 4u;
+    vob[i] = b_k[i] * M * 4u + (b_col[i] - col0) * 4u;
+  }
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
+  auto dma_piece = [&](unsigned buf, unsigned k0, int i) {   // i = 0, 1: A; 2, 3: B
+    const unsigned kc = min(k0, K - G::BK);
+    const bool is_a = i < 2;
+    const int j = is_a ? i : i - 2;
+    unsigned long long base = is_a ? (unsigned long long)(A + (size_t)row0 * K + kc) : (unsigned long long)(B + (size_t)kc * M + col0);
+    const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)base), bhi = __builtin_amdgcn_readfirstlane((unsigned)(base >> 32));
+    base = ((unsigned long long)bhi << 32) | blo;
+    const unsigned la = lds_base + buf * G::STAGE_BYTES + (is_a ? 0 : G::A_BYTES) + (wave + 4 * j) * 1024;
+    const unsigned vo = is_a ? voa[j] : vob[j];
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(vo), "s"(base), "s"(la) : "memory");
+  };
+
+  // per-lane fragment addresses inside a stage
+  const unsigned a_row = wm * 32 + lo;
+  const unsigned a_base = a_row * (G::BK * 4), a_swz = hi ^ ((a_row >> 1) & 7u);               // chunk (2 kg + hi) ^ swz(row)
+  const unsigned b_base = G::A_BYTES + (4 * hi) * (G::BN * 4) + ((((wn * 32 + lo) >> 2) ^ (8 * hi)) * 16) + (lo & 3u) * 4;
+
+  f32x16 acc = (f32x16)0.0f;
+  struct Frags { f32x4 a; float b[4]; };
+  auto read_group = [&](unsigned buf, int kg, Frags &f) {
+    const char *base = smem + buf * G::STAGE_BYTES;
+    f.a = *(const f32x4 *)(base + a_base + (((unsigned)(2 * kg) ^ a_swz) * 16));
+#pragma unroll
+    for (int p = 0; p < 4; ++p) f.b[p] = *(const float *)(base + b_base + (kg * 8 + p) * (G::BN * 4));
+  };
+  auto mfma_group = [&](const Frags &f) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[p], f.b[p], acc, 0, 0, 0);
+  };
+  // C (+)= accumulator: lane owns column lo of 16 rows
+  auto write_tile = [&](bool accumulate) {
+    const unsigned col = col0 + wn * 32 + lo;
+    if (col < M) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const unsigned row = row0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        if (row < N) {
+          float *dst = C + (size_t)row * M + col;
+          *dst = accumulate ? acc[r] + *dst : acc[r];
+        }
+      }
+    }
+  };
+
+  const unsigned num_tiles = (K + G::BK - 1) / G::BK, steady = num_tiles - 1;
+  const bool short_k = K < G::BK;   // a single partial slab: the per-lane clamped form, at the start of stage 0
+  // prologue: slabs 0 .. NS-2 (slab NS-1 is requested piece by piece during slab 0); wait for slab 0
+  if (short_k) {
+#pragma unroll
+    for (int s = 0; s < G::NS - 1; ++s) stage(s, s * G::BK);
+  } else {
+#pragma unroll
+    for (int s = 0; s < G::NS - 1; ++s)
+#pragma unroll
+      for (int i = 0; i < G::L; ++i) dma_piece(s, s * G::BK, i);
+  }
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"((G::NS - 2) * G::L) : "memory");
+  __builtin_amdgcn_s_barrier();
+
+  // One slab that has a successor.  The wavefront's MFMAs are one dependent chain: the second MFMA of a group cannot issue
+  // before the first has gone through the pipe, so that is where everything else goes.  After the first MFMA of group g:
+  // DMA piece g of slab t+NS-1 (into the stage slab t-1 left at the last hand-over) and the fragment reads of the NEXT
+  // group (by that group's first MFMA they are three MFMAs old: the `s_waitcnt lgkmcnt(0)` the compiler puts there is
+  // free).  The slab hand-over -- wait for slab t+1 (all but the pieces of the NS-2 slabs requested after it), barrier,
+  // first fragments of slab t+1 -- sits in the same place of the fourth group.
+  Frags f0, f1;
+  read_group(0, 0, f0);
+  unsigned buf = 0;
+  auto group = [&](const Frags &cur, auto &&meanwhile) {
+    __builtin_amdgcn_sched_barrier(0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[0], cur.b[0], acc, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    meanwhile();
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int p = 1; p < 4; ++p) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[p], cur.b[p], acc, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto slab = [&](unsigned t) {
+    const unsigned next = (buf + 1) % G::NS, refill = (buf + G::NS - 1) % G::NS, kr = (t + G::NS - 1) * G::BK;
+    group(f0, [&] { dma_piece(refill, kr, 0); read_group(buf, 1, f1); });
+    group(f1, [&] { dma_piece(refill, kr, 1); read_group(buf, 2, f0); });
+    group(f0, [&] { dma_piece(refill, kr, 2); read_group(buf, 3, f1); });
+    group(f1, [&] {
+      dma_piece(refill, kr, 3);
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((G::NS - 2) * G::L) : "memory");   // slab t+1 landed; this stage read out
+      __builtin_amdgcn_s_barrier();
+      read_group(next, 0, f0);
+    });
+    buf = next;
+  };
+  bool flushed = false;
+  for (unsigned t0 = 0; t0 < steady; t0 += G::CHUNK) {
+    const unsigned tend = min(t0 + (unsigned)G::CHUNK, steady);
+    for (unsigned t = t0; t < tend; ++t) slab(t);
+    if (tend < steady) {   // the flush rule of tile_body (with BK = 32, "more than 32 k follow" == a further steady slab)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      write_tile(flushed);
+      acc = (f32x16)0.0f;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      flushed = true;
+    }
+  }
+  {
+    const int groups = (int)((K - steady * G::BK) / 8);   // the last slab, full or partial
+    const int shift = short_k ? 0 : 4 - groups;            // fetched as the LAST 32 k of the matrix: its groups start further in
+    for (int kg = 0; kg < groups; ++kg) {
+      read_group(buf, kg + shift, f0);
+      mfma_group(f0);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // trailing (clamped, never read) refills
+  write_tile(flushed);
+}
+
+template <typename G = Small>
+int launch_small(hipStream_t s, const Problem &p) {
+  const unsigned tiles_n = (p.n + G::BM - 1) / G::BM, tiles_m = (p.m + G::BN - 1) / G::BN;
+  static unsigned long long configured = 0;
+  if (int e = ensure_dynamic_lds((const void *)mfma_f32_small_kernel<G>, G::LDS_BYTES, configured)) return e;
+  (void)hipGetLastError();
+  hipLaunchKernelGGL((mfma_f32_small_kernel<G>), dim3(tiles_n * tiles_m), dim3(G::THREADS), G::LDS_BYTES, s, (const float *)p.a,
+                     (const float *)p.b, (float *)p.c, p.n, p.k, p.m, tiles_n, tiles_m, band_rows(G::BM, G::BN, G::PER_CU));
+  return (int)hipGetLastError();
+}
+
 // ---- stream-K (round 3): problems of a few partial rounds of tiles ------------------------------------------------
 // A launch runs in whole rounds of resident workgroups, so 2560^3 (400 tiles of 128 x 128 for 512 slots) or 3072^3 (576
 // tiles: one full round and an eighth) leave a large part of the chip idle in their last round.  Here the job's
@@ -856,6 +1064,7 @@ constexpr VariantInfo kVariants[] = {
     info_of<T128x256>(33, "mfma_f32_128x256x16_w4x2_flush4096"),
     info_of<T256x256>(8, "mfma_f32_256x256x16_w8_flush4096"),
     info_of<T128x128>(35, "mfma_f32_128x128x32_w4x2_flush4096"),
+    info_of<Small>(64, "mfma_f32_64x64x32_w4x2_flush4096"),
     info_of<X128x256x32_2lvl>(0, "mfma_f32_128x256x32_w4_2lvl"),
     info_of<X256x256_single>(3, "mfma_f32_256x256x16_w8"),
 };
@@ -899,13 +1108,51 @@ static bool streamk_wins(const Problem &p) {
   return sk < 0.99 * whole;
 }
 
+// K chunks of the shape-adaptive split-K rule for `tiles` tiles of 128 x 128 (mfma_f32_splitk): when the tiles leave a quarter
+// or more of the CUs without a workgroup, as many copies of the tile grid as fit the 512 places, at most 8, chunks >= 256 k
+static unsigned auto_split_chunks(unsigned long long tiles, unsigned k) {
+  unsigned s = tiles <= 192 ? (unsigned)(512 / tiles) : 1;   // 256 tiles already give every CU a workgroup (2048^3: 125 vs 112 TF split)
+  if (s > 8) s = 8;
+  while (s > 1 && k / s < 256) --s;
+  return s;
+}
+
+// The 64 x 64 geometry (launch_small) addresses a tile's rows with 32-bit byte offsets from a 64-bit base.
+static bool small_fits(const Problem &p) {
+  return !p.a_transposed && 64ull * p.k * 4ull < (1ull << 32) && 32ull * p.m * 4ull < (1ull << 32);
+}
+
+// Below a round of 128 x 128 tiles: the 64 x 64 geometry (whole K, no second kernel) against the 128 x 128 one with its
+// split-K rule, in microseconds, fitted to profiles/r03x_f32_small_tile_k_slope.txt and r03x_f32_small_shapes.txt:
+//   64 x 64:   3.5 + slabs x 0.52 (one workgroup per CU: a lone dependent MFMA chain per SIMD) or x 0.90 (two per CU);
+//              more than 512 tiles never (a second round: the 128 x 128 tile's half bytes per flop win);
+//   128 x 128: 5 + slabs x 1.79 (one workgroup per CU) or x 3.49 (two); a split adds the partial planes' round trip and
+//              the reduce kernel: + 13.5.
+// 1024^3 105 vs 75 TF, 1024 x 512 x 1024 89 vs 40, 768^3 56 vs 34, 512^3 23 vs 12, 1280^3 98 vs 91; split-K keeps the long-K
+// shapes with few tiles (512 x 4096 x 512: 53 vs 31) and 1536^3 (576 tiles of 64 x 64).  Decided on the whole job
+// (Problem::n_total), like the split itself, so row slabs keep the bits of the one-launch result.
+static bool small_wins(const Problem &p) {
+  if (!small_fits(p) || p.k < 32) return false;
+  const unsigned rows = p.n_total ? p.n_total : p.n;
+  const unsigned long long t64 = (unsigned long long)((rows + 63) / 64) * ((p.m + 63) / 64), t128 = (unsigned long long)((rows + 127) / 128) * ((p.m + 127) / 128);
+  if (t64 > 512) return false;
+  const double slabs = (p.k + 31) / 32;
+  const double t_small = 3.5 + slabs * (t64 <= 256 ? 0.52 : 0.90);
+  const unsigned s = tuning(TUNE_F32_SPLITK) == 1 ? 1 : auto_split_chunks(t128, p.k);
+  const double t_128 = (s > 1 ? 18.5 : 5.0) + (slabs / s) * (t128 * s <= 256 ? 1.79 : 3.49);
+  return t_small < t_128;
+}
+
 int mfma_f32_auto_variant(const Problem &p) {
   // relative efficiencies at 16384^3 at the end of round 2, all three with the pinned schedule and scalar-base DMA:
   // 128x256 as two 4-wavefront workgroups per CU (33) 152.2 TF, 256x256 / 8 wavefronts (8) 150.8, 128x128x32 (35) 151.2
   // (profiles/r02z_f32_scalar_base_dma.log, r02z_f32_small_tile_scalar_base_dma.log); small and mid-size shapes:
   // r02z_f32_small_shapes_after_scalar_base_dma.log
-  if (tuning(TUNE_F32_SPLITK) < 0 && streamk_wins(p)) return 35;   // the 128 x 128 geometry is the one stream-K runs on
-  return pick_tile(kAutoCands, 3, p.n, p.m);
+  const int knob = tuning(TUNE_F32_SPLITK);
+  if (knob < 0 && streamk_wins(p)) return 35;   // the 128 x 128 geometry is the one stream-K runs on
+  const int v = pick_tile(kAutoCands, 3, p.n, p.m);
+  if (v == 35 && (knob < 0 || knob == 1) && small_wins(p)) return 64;   // (a forced split or stream-K means the 128 x 128 geometry)
+  return v;
 }
 
 bool mfma_f32_serves(const Problem &p) {
@@ -919,6 +1166,7 @@ int mfma_f32_resolve(const Problem &p, int variant) {
   if (!mfma_f32_serves(p)) return -1;
   if (p.a_transposed) return 8;                       // K x N A: the 256 x 256 geometry, whatever the knob says
   if (variant < 0) variant = mfma_f32_auto_variant(p);
+  if (variant == 64 && !small_fits(p)) return -1;
   return find_variant(variant) ? variant : -1;
 }
 
@@ -940,7 +1188,7 @@ int mfma_f32_splitk(const Problem &p, int variant) {
   if (knob >= 1) s = (unsigned)knob;
   else if (tuning(TUNE_F32_VARIANT) >= 0) s = 1;          // a pinned geometry is run as pinned
   else if (streamk_wins(p)) return 0;                     // a few partial rounds of tiles: stream-K
-  else s = tiles <= 192 ? (unsigned)(512 / tiles) : 1;   // 256 tiles already give every CU a workgroup (2048^3: 125 vs 112 TF split)
+  else return (int)auto_split_chunks(tiles, p.k);
   if (s > 8) s = 8;
   while (s > 1 && p.k / s < 256) --s;                     // chunks of at least 256 k
   return (int)s;
@@ -977,6 +1225,7 @@ int launch_mfma_f32(hipStream_t s, const Problem &p, int variant) {
       if (splits == 9) return sdma_fits(p, 32) ? launch_streamk<T128x128>(s, p) : launch_streamk<T128x128v>(s, p);
       return sdma_fits(p, 32) ? launch_geo<T128x128>(s, p, (unsigned)splits) : launch_geo<T128x128v>(s, p, (unsigned)splits);
     }
+    case 64: return launch_small<Small>(s, p);
     case 0: return launch_geo<X128x256x32_2lvl>(s, p);
     case 3: return launch_geo<X256x256_single>(s, p);
   }

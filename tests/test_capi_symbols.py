@@ -122,17 +122,17 @@ def test_tuning_environment_is_read_at_first_use():
 
 
 def test_f32_variant_ids_of_the_product():
-    """The library holds five fp32 geometries: the three MM_PATH_AUTO picks from and two cross-check ones; every other
+    """The library holds six fp32 geometries: the four MM_PATH_AUTO picks from and two cross-check ones; every other
     id (the lab's) names nothing here.  tests/test_gpu_parity.py iterates over exactly this list."""
     valid = []
     try:
-        for v in range(0, 64):
+        for v in range(0, 80):
             g.set_tuning("f32_variant", v)
             if g.kernel_name(g.make_config("float"), 4096, 4096, 4096) != "unsupported":
                 valid.append(v)
     finally:
         g.set_tuning("f32_variant", -1)
-    assert valid == [0, 3, 8, 33, 35]
+    assert valid == [0, 3, 8, 33, 35, 64]
 
 
 def test_kernel_info_binding():

@@ -351,20 +351,20 @@ def test_lab_library_runs_the_retired_schedules_and_gates_its_ablations():
 
 
 @pytest.mark.parametrize("path_name", ["auto", "split"])
-@pytest.mark.parametrize("shape", [(384, 256, 320), (512, 1024, 512), (2304, 256, 2304)], ids=lambda s: "x".join(map(str, s)))
+@pytest.mark.parametrize("shape", [(384, 256, 320), (512, 1024, 512), (384, 4096, 256), (2304, 256, 2304)], ids=lambda s: "x".join(map(str, s)))
 def test_enqueue_is_capturable_into_a_hip_graph(path_name, shape):
     """mm_gemm_enqueue issues only stream-ordered work (kernels; for MM_PATH_SPLIT also hipMallocAsync / hipFreeAsync),
     so a launch-bound loop of small products can be captured once and replayed as a hipGraph (here through torch's
     graph capture, which puts its capture stream in hipStreamCaptureModeGlobal)."""
     import torch
     path = g.PATH_SPLIT if path_name == "split" else g.PATH_AUTO
-    n, k, m = shape     # whole tiles / split-K (4 chunks + the ordered reduction) / stream-K (+ its fix-up kernel) under AUTO
+    n, k, m = shape     # whole tiles (64 x 64 geometry twice) / split-K (8 chunks + the ordered reduction) / stream-K (flags memset + hand-over kernel) under AUTO
     if path_name == "split" and shape != (384, 256, 320):
         pytest.skip("one shape is enough for the opt-in path")
     a, b = _oracle.fill("float", n, k, m)
     ta, tb = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
     if path_name == "auto":
-        expect = {(384, 256, 320): "flush4096", (512, 1024, 512): "splitk4", (2304, 256, 2304): "streamk"}[shape]
+        expect = {(384, 256, 320): "64x64x32", (512, 1024, 512): "64x64x32", (384, 4096, 256): "splitk8", (2304, 256, 2304): "streamk"}[shape]
         assert expect in g.kernel_name(g.make_config("float"), n, k, m)
     outs = [torch.zeros((n, m), dtype=torch.float32, device="cuda") for _ in range(4)]
     want = g.matmul(ta, tb, path=path).clone()      # also warms up: function attributes, pool configuration

@@ -47,7 +47,7 @@ def test_f32_mfma_default_vs_blas_and_exact(shape):
     assert np.max(np.abs(c - exact) / exact) < F32_TOL
 
 
-F32_VARIANTS = [33, 8, 35, 0, 3]   # the product's geometries (tests/test_capi_symbols.py pins this list to the library's)
+F32_VARIANTS = [33, 8, 35, 64, 0, 3]   # the product's geometries (tests/test_capi_symbols.py pins this list to the library's)
 
 
 @pytest.mark.parametrize("variant", F32_VARIANTS)
@@ -67,7 +67,7 @@ def test_f32_mfma_every_variant(variant, shape):
                                    (129, 12320, 260)],
                          ids=lambda s: "x".join(map(str, s)))
 def test_f32_shipped_geometries_are_bit_identical_to_each_other(shape):
-    """The three geometries MM_PATH_AUTO picks from -- 128x256 (33), 256x256 (8), 128x128x32 (35) -- issue the same MFMAs
+    """The four geometries MM_PATH_AUTO picks from -- 128x256 (33), 256x256 (8), 128x128x32 (35), 64x64x32 (64) -- issue the same MFMAs
     per output element in the same k order and flush into C at the same k (every 4096; one, two and three flushes in
     these shapes), so whichever the shape-adaptive pick takes, the bits are the same; also with mixed signs.  The
     compiler-scheduled single-chain geometry (3) has the same order without the flush: identical while K <= 4096 + a slab."""
@@ -76,11 +76,11 @@ def test_f32_shipped_geometries_are_bit_identical_to_each_other(shape):
     a = rng.uniform(-3, 10, size=(n, k)).astype(np.float32)
     b = rng.uniform(-3, 10, size=(k, m)).astype(np.float32)
     out = {}
-    for v in (8, 33, 35, 3):
+    for v in (8, 33, 35, 64, 3):
         g.set_tuning("f32_variant", v)
         out[v], _ = g.matmul_capi(a, b)
     g.set_tuning("f32_variant", -1)
-    assert np.array_equal(out[8], out[33]) and np.array_equal(out[8], out[35])
+    assert np.array_equal(out[8], out[33]) and np.array_equal(out[8], out[35]) and np.array_equal(out[8], out[64])
     if k <= 4096 + 32:
         assert np.array_equal(out[8], out[3])
     else:
@@ -88,8 +88,64 @@ def test_f32_shipped_geometries_are_bit_identical_to_each_other(shape):
         assert np.max(np.abs(out[8] - out[3]) / np.maximum(np.abs(out[3]), 1e-3)) < 1e-3
 
 
-@pytest.mark.parametrize("shape,splitk", [((1024, 1024, 1024), -1), ((1024, 1024, 1024), 2), ((300, 2048, 272), 8), ((129, 4104, 132), 3),
-                                          ((513, 1032, 520), -1), ((1536, 1536, 1536), -1), ((640, 520, 384), 2)],
+@pytest.mark.parametrize("shape", [(1024, 1024, 1024), (513, 1032, 520), (1000, 96, 1500), (768, 768, 768), (1061, 512, 1024), (512, 512, 512),
+                                   (1280, 1280, 1280), (1024, 4128, 1024)], ids=lambda s: "x".join(map(str, s)))
+def test_f32_small_problems_take_the_64x64_geometry_with_the_bits_of_the_others(shape):
+    """Below a round of 128 x 128 tiles the shape-adaptive pick takes the 64 x 64 geometry (one 32 x 32 accumulator per
+    wavefront, whole K, no second kernel) where its time model beats split-K.  Same MFMA chain per output element and
+    the same flush rule as the other shipped geometries: identical bits to the unsplit 128 x 128 and 256 x 256 kernels."""
+    n, k, m = shape
+    rng = np.random.default_rng(n + k)
+    a = rng.uniform(-3, 10, size=(n, k)).astype(np.float32)
+    b = rng.uniform(-3, 10, size=(k, m)).astype(np.float32)
+    name = g.kernel_name(g.make_config("float"), n, k, m)
+    info = g.kernel_info(g.make_config("float"), n, k, m)
+    assert (info.tile_n, info.tile_m, info.tile_k, info.wavefronts) == (64, 64, 32, 4)
+    c, _ = g.matmul_capi(a, b)
+    out = {}
+    try:
+        g.set_tuning("f32_splitk", 1)
+        for v in (35, 8):
+            g.set_tuning("f32_variant", v)
+            out[v], _ = g.matmul_capi(a, b)
+    finally:
+        g.set_tuning("f32_splitk", -1)
+        g.set_tuning("f32_variant", -1)
+    assert name == "mfma_f32_64x64x32_w4x2_flush4096", name
+    assert np.array_equal(c, out[35]) and np.array_equal(c, out[8])
+    exact = a.astype(np.float64) @ b.astype(np.float64)
+    scale = np.abs(a.astype(np.float64)) @ np.abs(b.astype(np.float64))
+    assert np.max(np.abs(c - exact) / scale) < (2e-6 if k <= 2048 else 5e-6)   # longer unsplit chains drift further
+
+
+@pytest.mark.parametrize("shape", [(64, 8, 64), (1, 8, 4), (65, 24, 68), (70, 16, 132), (129, 40, 260), (64, 32, 64), (200, 8224, 136), (3, 4120, 8)],
+                         ids=lambda s: "x".join(map(str, s)))
+def test_f32_64x64_geometry_edges(shape):
+    """f32_variant 64 pinned on shapes its own rule would not take: K shorter than a slab (the per-lane clamped staging),
+    a partial last slab (fetched as the last 32 k of the matrix and consumed from the end of its stage), ragged N / M,
+    flush boundaries; bit-identical to the 128 x 128 geometry."""
+    n, k, m = shape
+    rng = np.random.default_rng(n * k)
+    a = rng.uniform(-3, 10, size=(n, k)).astype(np.float32)
+    b = rng.uniform(-3, 10, size=(k, m)).astype(np.float32)
+    try:
+        g.set_tuning("f32_splitk", 1)
+        g.set_tuning("f32_variant", 64)
+        assert g.kernel_name(g.make_config("float"), n, k, m) == "mfma_f32_64x64x32_w4x2_flush4096"
+        c64, _ = g.matmul_capi(a, b)
+        g.set_tuning("f32_variant", 35)
+        c35, _ = g.matmul_capi(a, b)
+    finally:
+        g.set_tuning("f32_splitk", -1)
+        g.set_tuning("f32_variant", -1)
+    assert np.array_equal(c64, c35)
+    exact = a.astype(np.float64) @ b.astype(np.float64)
+    scale = np.abs(a.astype(np.float64)) @ np.abs(b.astype(np.float64))
+    assert np.max(np.abs(c64 - exact) / scale) < 2e-6
+
+
+@pytest.mark.parametrize("shape,splitk", [((512, 4096, 512), -1), ((1024, 1024, 1024), 2), ((300, 2048, 272), 8), ((129, 4104, 132), 3),
+                                          ((257, 4104, 260), -1), ((1536, 1536, 1536), -1), ((640, 520, 384), 2), ((1024, 1024, 1024), 4)],
                          ids=lambda v: "x".join(map(str, v)) if isinstance(v, tuple) else f"splitk{v}")
 def test_f32_split_k_for_small_problems_is_deterministic_and_accurate(shape, splitk):
     """problems that cannot fill the chip with whole 128 x 128 tiles are cut along K into up to 8

@@ -453,3 +453,43 @@ def test_pingpong_16x16_kxn_a_gather_f16_and_i8():
                 assert kr == 16 * (l >> 4) + 8 * h2 + j and lc * 16 + a % 16 == wm * 128 + rb * 16 + (l & 15)
         b64_half_banks_disjoint(addr, range(0, 32))
         b64_half_banks_disjoint(addr, range(32, 64))
+
+
+# ---------------------------------------------------------------- fp32 64 x 64 geometry (round 3) ------------
+# gemm_hls_amd/csrc/mm_mfma_f32.hip: mfma_f32_small_kernel.  A slab [64 rows][8 chunks of 4 k], chunk ^ (row >> 1) & 7;
+# B slab [32 k][16 chunks of 4 columns], chunk ^ 8 for k & 4, read one float per lane (ds_read_b32 / ds_read2st64_b32).
+def test_f32_small_a_image_roundtrip_and_banks():
+    lds = {}
+    for s in range(64 * 8):                       # DMA: 16-B slot s <- A[row = s >> 3][logical chunk (s & 7) ^ swz(row)]
+        row, pc = s >> 3, s & 7
+        lds[s * 16] = (row, pc ^ ((row >> 1) & 7))
+    assert len({v for v in lds.values()}) == 64 * 8          # a permutation of the slab
+    for wm, kg in itertools.product(range(2), range(4)):
+        def addr(l):
+            lo, hi = l & 31, l >> 5
+            row = wm * 32 + lo
+            return row * 128 + (((2 * kg) ^ (hi ^ ((row >> 1) & 7))) * 16)
+        for l in range(64):
+            row, lc = lds[addr(l)]
+            assert row == wm * 32 + (l & 31) and lc == 2 * kg + (l >> 5)    # k = 8 kg + 4 (lane >> 5) + 0..3
+        assert_conflict_free_b128(addr)
+
+
+def test_f32_small_b_image_roundtrip_and_banks():
+    lds = {}
+    for s in range(32 * 16):                      # DMA: slot s <- B[k = s >> 4][column chunk (s & 15) ^ (8 if k & 4)]
+        k, pc = s >> 4, s & 15
+        lds[s * 16] = (k, pc ^ ((k & 4) << 1))
+    assert len({v for v in lds.values()}) == 32 * 16
+    for wn, kg, p in itertools.product(range(2), range(4), range(4)):
+        def addr(l):
+            lo, hi = l & 31, l >> 5
+            return (4 * hi) * 256 + ((((wn * 32 + lo) >> 2) ^ (8 * hi)) * 16) + (lo & 3) * 4 + (kg * 8 + p) * 256
+        banks = set()
+        for l in range(64):
+            a = addr(l)
+            k, chunk = lds[a - a % 16]
+            assert k == kg * 8 + p + 4 * (l >> 5)                            # MFMA p: k = p (lanes < 32), p + 4 (lanes >= 32)
+            assert chunk * 4 + (a % 16) // 4 == wn * 32 + (l & 31)           # column lane & 31 of the wavefront's 32
+            banks.add((a // 4) % 64)
+        assert len(banks) == 64                                              # one dword per bank: the 64 lanes in one pass

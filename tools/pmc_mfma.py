@@ -20,7 +20,7 @@ PASSES = [
     ["TCC_HIT_sum", "TCC_MISS_sum"],
     ["SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_VMEM", "SQ_INSTS_VALU", "SQ_INSTS_LDS"],
 ]
-KERNEL = {"f32": "mfma_f32_kernel", "f64": "mfma_f64_kernel", "f16": "mfma_f16_", "minplus": "valu_tile_",
+KERNEL = {"f32": "mfma_f32_", "f64": "mfma_f64_kernel", "f16": "mfma_f16_", "minplus": "valu_tile_",
           "uint8": "mfma_i8_", "split": "mfma_f32_split_kernel"}
 VARIANT = None  # --variant: pins the family's tuning knob (sweep.py --variants) for every pass
 

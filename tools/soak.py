@@ -40,7 +40,8 @@ CASES = [
     ("half",         "half",    ("Multiply", "Add"), torch.float16, 16384, 150, "f16_variant", 100),
     ("half K%64=32", "half",    ("Multiply", "Add"), torch.float16, 8224, 100, "f16_variant", 0),    # plain ping-pong (K % 64 != 0)
     # round 3: the two-kernel launches of small / mid-size fp32 problems; against whole tiles they differ by summation order only
-    ("float split-K", "float",  ("Multiply", "Add"), torch.float32, 1024, 300, "f32_splitk", 1),     # 1061 x 1024 x 1024: 72 tiles, 4 K chunks
+    ("float split-K", "float",  ("Multiply", "Add"), torch.float32, 4096, 300, "f32_splitk", 1, g.PATH_AUTO, (421, 4096, 256)),   # 8 tiles, 8 K chunks
+    ("float 64x64",  "float",   ("Multiply", "Add"), torch.float32, 1024, 300, "f32_variant", 35),   # 1061 x 1024 x 1024: the small-problem geometry (one MFMA chain per wavefront)
     ("float stream-K", "float", ("Multiply", "Add"), torch.float32, 2304, 200, "f32_splitk", 1),     # 2341 x 2304 x 2304: 342 tiles over 512 workgroups
     ("double",       "double",  ("Multiply", "Add"), torch.float64, 4096, 40, "f64_variant", 2),     # 2: round-1 schedule
     ("uint8_t",      "uint8_t", ("Multiply", "Add"), torch.uint8, 16384, 150, "i8_variant", 0),
@@ -51,15 +52,15 @@ CASES = [
 for label, dtype, ops, tdt, n, reps, knob, other, *rest in CASES:
     path = rest[0] if rest else g.PATH_AUTO
     reps *= args.scale
-    rows = n + 37                                        # ragged N on purpose
-    a = torch.empty((rows, n), dtype=tdt, device=dev)
-    b = torch.empty((n, n), dtype=tdt, device=dev)
+    rows, kk, mm = rest[1] if len(rest) > 1 else (n + 37, n, n)   # ragged N on purpose
+    a = torch.empty((rows, kk), dtype=tdt, device=dev)
+    b = torch.empty((kk, mm), dtype=tdt, device=dev)
     g._check(g.lib().mm_fill_device(0, g.DTYPES[dtype], a.data_ptr(), a.numel(), 5))
     g._check(g.lib().mm_fill_device(0, g.DTYPES[dtype], b.data_ptr(), b.numel(), 6))
     if dtype == "half":                                  # keep the sums finite: an all-inf result compares equal whatever happened
         a.mul_(2.0 ** -6)
         b.mul_(2.0 ** -6)
-    name = g.kernel_name(g.make_config(dtype, *ops, path), rows, n, n)
+    name = g.kernel_name(g.make_config(dtype, *ops, path), rows, kk, mm)
     ref = g.matmul(a, b, dtype, *ops, path=path).clone()
     torch.cuda.synchronize()
     if dtype in ("half", "float", "double"):
@@ -95,7 +96,7 @@ for label, dtype, ops, tdt, n, reps, knob, other, *rest in CASES:
         if not torch.equal(c.view(torch.uint8), ref.view(torch.uint8)):
             bad += 1
     torch.cuda.synchronize()
-    print(f"{label:24s} {name:36s} {rows}x{n}x{n}: {reps} launches, {bad} differing results, "
+    print(f"{label:24s} {name:36s} {rows}x{kk}x{mm}: {reps} launches, {bad} differing results, "
           f"equal to independent schedule: {same_as_other}, {time.perf_counter()-t0:.1f} s", flush=True)
     assert bad == 0
 print("soak ok")
