@@ -1160,11 +1160,59 @@ bool mfma_f32_serves(const Problem &p) {
   return !p.a_transposed || (p.n >= 4 && p.n % 4 == 0);  // K x N A is DMA'd in 16-B chunks along N
 }
 
+// K x N A (MM_TRANSPOSED_A) outside whole rounds of 256 x 256 tiles.  The K x N kernel exists in one geometry, so a problem
+// that does not fill rounds of it pays dearly -- 1024^3 9 TF against 101 row-major, 2048^3 38 against 141, 6144^3 113
+// against 150 (profiles/r03y_f32_transposed_a_sizes.txt).  Under the shape-adaptive pick such a problem is therefore
+// transposed into a stream-ordered workspace first (N x K x 4 B, read once and written once: 2.5 % of the product at
+// 6144^3, less above) and then runs whatever the row-major rules choose -- with their bits: the result equals the row-major
+// call's.  Whole rounds (4096^3, 8192^3, 16384^3 ...) and a pinned f32_variant keep the K x N kernel as it is.
+static bool transposes_first(const Problem &p, int variant_knob) {
+  if (!p.a_transposed || variant_knob >= 0) return false;
+  const unsigned long long tiles = (unsigned long long)((p.n + 255) / 256) * ((p.m + 255) / 256), rounds = (tiles + 255) / 256;
+  if ((double)tiles >= 0.93 * (double)(rounds * 256)) return false;
+  return (unsigned long long)p.n * p.k * sizeof(float) <= (2ull << 30);
+}
+static Problem as_row_major(const Problem &p) {
+  Problem q = p;
+  q.a_transposed = false;
+  return q;
+}
+
+// dst[n][k] = src[k][n]: 64 x 64 tiles through LDS, 16-byte accesses on both sides (N % 4 == 0 and K % 8 == 0 here)
+__global__ __launch_bounds__(256) void transpose_kxn_kernel(const float *__restrict__ src, float *__restrict__ dst, unsigned K, unsigned N) {
+  __shared__ float tile[64][65];
+  const unsigned blocks_n = (N + 63) / 64;   // 1-D grid: either dimension may exceed the 65535 of gridDim.y
+  const unsigned k0 = (blockIdx.x / blocks_n) * 64, n0 = (blockIdx.x % blocks_n) * 64;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const unsigned idx = threadIdx.x + 256 * i, r = idx >> 4, c = (idx & 15u) * 4;
+    if (k0 + r < K && n0 + c < N) {
+      const f32x4 v = *(const f32x4 *)(src + (size_t)(k0 + r) * N + n0 + c);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) tile[r][c + j] = v[j];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const unsigned idx = threadIdx.x + 256 * i, r = idx >> 4, c = (idx & 15u) * 4;
+    if (n0 + r < N && k0 + c < K) {
+      f32x4 v;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = tile[c + j][r];
+      *(f32x4 *)(dst + (size_t)(n0 + r) * K + k0 + c) = v;
+    }
+  }
+}
+
 // The one place that decides which geometry a (problem, f32_variant knob) pair runs: mm_kernel_name,
 // mm_kernel_info and the launcher all go through it.  Returns the variant id, or -1 when unsupported.
 int mfma_f32_resolve(const Problem &p, int variant) {
   if (!mfma_f32_serves(p)) return -1;
-  if (p.a_transposed) return 8;                       // K x N A: the 256 x 256 geometry, whatever the knob says
+  if (p.a_transposed) {
+    if (transposes_first(p, variant)) return mfma_f32_resolve(as_row_major(p), variant);
+    return 8;                                          // K x N A: the 256 x 256 geometry, whatever the knob says
+  }
   if (variant < 0) variant = mfma_f32_auto_variant(p);
   if (variant == 64 && !small_fits(p)) return -1;
   return find_variant(variant) ? variant : -1;
@@ -1179,7 +1227,8 @@ int mfma_f32_resolve(const Problem &p, int variant) {
 // for row-major A and variant 35).  Row slabs of a bigger job (Problem::n_total) never take stream-K: its unit ranges would
 // depend on the slab, and with them a row's summation order.
 int mfma_f32_splitk(const Problem &p, int variant) {
-  if (p.a_transposed || variant != 35) return 1;
+  if (p.a_transposed) return transposes_first(p, tuning(TUNE_F32_VARIANT)) ? mfma_f32_splitk(as_row_major(p), variant) : 1;
+  if (variant != 35) return 1;
   const int knob = tuning(TUNE_F32_SPLITK);
   if (knob == 0 || knob == 9) return (p.k % 32 == 0 && p.k >= 64) ? knob : 1;   // stream-K forced: 0 = ordered hand-over (the one auto takes), 9 = fix-up kernel
   const unsigned rows = p.n_total ? p.n_total : p.n;   // of the whole job (Problem::n_total)
@@ -1215,7 +1264,26 @@ static bool sdma_fits(const Problem &p, unsigned bk) {
 int launch_mfma_f32(hipStream_t s, const Problem &p, int variant) {
   const int v = mfma_f32_resolve(p, variant);
   if (v < 0) return kErrNotSupported;
-  if (p.a_transposed) return sdma_fits(p, 16) ? launch_geo<T256x256, true>(s, p) : launch_geo<T256x256v, true>(s, p);
+  if (p.a_transposed) {
+    if (!transposes_first(p, variant)) return sdma_fits(p, 16) ? launch_geo<T256x256, true>(s, p) : launch_geo<T256x256v, true>(s, p);
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    hipMemPool_t pool = nullptr;
+    if (int rc = workspace_pool(dev, &pool)) return rc;
+    float *an = nullptr;
+    if ((e = hipMallocFromPoolAsync((void **)&an, (size_t)p.n * p.k * sizeof(float), pool, s)) != hipSuccess) return (int)e;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(transpose_kxn_kernel, dim3(((p.n + 63) / 64) * ((p.k + 63) / 64)), dim3(256), 0, s, (const float *)p.a, an, p.k, p.n);
+    int rc = (int)hipGetLastError();
+    if (rc == 0) {
+      Problem q = as_row_major(p);
+      q.a = an;
+      rc = launch_mfma_f32(s, q, variant);
+    }
+    const hipError_t f = hipFreeAsync(an, s);
+    return rc ? rc : (int)f;
+  }
   switch (v) {
     case 33: return sdma_fits(p, 16) ? launch_geo<T128x256>(s, p) : launch_geo<T128x256v>(s, p);
     case 8: return sdma_fits(p, 16) ? launch_geo<T256x256>(s, p) : launch_geo<T256x256v>(s, p);

@@ -256,25 +256,52 @@ def test_f32_stream_k_launches_sharing_the_chip_make_progress_and_keep_their_bit
             assert torch.equal(c, alone[i]), names[i]
 
 
-@pytest.mark.parametrize("shape", [(516, 528, 528), (4, 16, 16), (300, 64, 272), (1024, 4112, 512), (260, 8, 4)],
+@pytest.mark.parametrize("native", [True, False], ids=["kxn_kernel", "shape_adaptive"])
+@pytest.mark.parametrize("shape", [(516, 528, 528), (4, 16, 16), (300, 64, 272), (1024, 4112, 512), (260, 8, 4), (1028, 1024, 1024), (2308, 512, 2304)],
                          ids=lambda s: "x".join(map(str, s)))
-def test_f32_mfma_transposed_a_layout(shape):
-    """MM_TRANSPOSED_A: A handed over as K x N (kernel/Memory.cpp:205-261, include/Utility.h:31-35)."""
+def test_f32_mfma_transposed_a_layout(shape, native):
+    """MM_TRANSPOSED_A: A handed over as K x N (kernel/Memory.cpp:205-261, include/Utility.h:31-35).  `kxn_kernel`: the
+    geometry pinned (f32_variant 8), which runs the K x N kernel -- slabs of A DMA'd as [k][row] -- whatever the shape.
+    `shape_adaptive`: problems that do not fill rounds of that kernel's 256 x 256 tiles are transposed into a workspace
+    first and then take the row-major rules (64 x 64 geometry, split-K, stream-K ...).  Either way the bits are those of
+    the row-major call under the same knobs."""
     n, k, m = shape
     a, b = _oracle.fill("float", n, k, m)
     at = np.ascontiguousarray(a.T)
     cfg = g.make_config("float", transposed_a=True)
-    assert g.kernel_name(cfg, n, k, m).startswith("mfma_f32")
-    c, _ = g.matmul_capi(at, b, transposed_a=True)
+    try:
+        if native:
+            g.set_tuning("f32_variant", 8)
+            g.set_tuning("f32_splitk", 1)
+        name = g.kernel_name(cfg, n, k, m)
+        name_rm = g.kernel_name(g.make_config("float"), n, k, m)
+        c, _ = g.matmul_capi(at, b, transposed_a=True)
+        c_rm, _ = g.matmul_capi(a, b)
+    finally:
+        g.set_tuning("f32_variant", -1)
+        g.set_tuning("f32_splitk", -1)
+    assert name.startswith("mfma_f32") and name == name_rm, (name, name_rm)
+    if native:
+        assert name == "mfma_f32_256x256x16_w8_flush4096"
     exact = a.astype(np.float64) @ b.astype(np.float64)
     rel = np.abs(c - exact) / exact
     assert rel.max() < F32_TOL, (np.unravel_index(np.argmax(rel), rel.shape), rel.max())
-    # and it is the same arithmetic as the row-major path: identical bits (split-K of small problems off: the K x N layout
-    # never splits, and a split changes the summation order)
-    g.set_tuning("f32_splitk", 1)
-    c_rm, _ = g.matmul_capi(a, b)
-    g.set_tuning("f32_splitk", -1)
     assert np.array_equal(c, c_rm)
+
+
+def test_f32_transposed_a_in_whole_rounds_keeps_the_kxn_kernel():
+    """4096^3 is exactly one round of 256 x 256 tiles: no workspace, the K x N kernel itself (and the row-major pick's bits)."""
+    import torch
+    n = k = m = 4096
+    assert g.kernel_name(g.make_config("float", transposed_a=True), n, k, m) == "mfma_f32_256x256x16_w8_flush4096"
+    a = torch.empty((n, k), device="cuda").uniform_(1, 10)
+    b = torch.empty((k, m), device="cuda").uniform_(1, 10)
+    at = a.t().contiguous()
+    free0 = torch.cuda.mem_get_info()[0]
+    c = g.matmul(at, b, transposed_a=True)
+    torch.cuda.synchronize()
+    assert free0 - torch.cuda.mem_get_info()[0] <= n * m * 4 + (8 << 20)      # C only: no N x K workspace appeared
+    assert torch.equal(c, g.matmul(a, b))
 
 
 def test_f32_mfma_transpose_detecting_inputs():
