@@ -109,8 +109,9 @@ int mm_free(int device, void *device_ptr);
 
 /* buffer.CopyFromHost / CopyToHost (RunHardware.cpp:142-144,189).  Blocking. */
 /* Stream-ordered workspace (MM_PATH_SPLIT: 6 bytes per element of A and B of the largest launch so far; the fp32
- * default path: the partial planes / scratch slots of its split-K and stream-K launches, a few MiB) is cached between
- * launches in a memory pool this library owns -- never in the process's default pool.  This waits for the device and
+ * default path: the partial planes / scratch slots of its split-K and stream-K launches, a few MiB, and for a K x N A
+ * that does not fill rounds of the K x N kernel's tiles its N x K copy, 4 bytes per element, at most 2 GiB) is cached
+ * between launches in a memory pool this library owns -- never in the process's default pool.  This waits for the device and
  * hands that memory back to the driver; the next launch that needs workspace allocates again. */
 int mm_release_workspace(int device);
 
