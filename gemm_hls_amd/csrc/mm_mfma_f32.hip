@@ -1098,6 +1098,7 @@ static const TileCandidate kAutoCands[] = {{33, 128, 256, 2, 1.00}, {8, 256, 256
 // split-K or the plain kernel, see mfma_f32_splitk).
 static bool streamk_wins(const Problem &p) {
   if (p.a_transposed || p.k % 32 != 0 || p.k < 256 || p.n_total) return false;
+  if ((unsigned long long)((p.n + 127) / 128) * ((p.m + 127) / 128) * (p.k / 32) >= (1ull << 31)) return false;   // units are counted in 32 bits
   const double tiles = (double)((p.n + 127) / 128) * ((p.m + 127) / 128);
   const unsigned tn = (p.n + 127) / 128, tm = (p.m + 127) / 128;
   const bool teams_4x4 = tn % 4 == 0 && tm % 4 == 0;               // streamk_team_shape: full sharing inside an XCD
@@ -1230,7 +1231,8 @@ int mfma_f32_splitk(const Problem &p, int variant) {
   if (p.a_transposed) return transposes_first(p, tuning(TUNE_F32_VARIANT)) ? mfma_f32_splitk(as_row_major(p), variant) : 1;
   if (variant != 35) return 1;
   const int knob = tuning(TUNE_F32_SPLITK);
-  if (knob == 0 || knob == 9) return (p.k % 32 == 0 && p.k >= 64) ? knob : 1;   // stream-K forced: 0 = ordered hand-over (the one auto takes), 9 = fix-up kernel
+  const unsigned long long sk_units = (unsigned long long)((p.n + 127) / 128) * ((p.m + 127) / 128) * (p.k / 32);   // the kernels count units in 32 bits
+  if (knob == 0 || knob == 9) return (p.k % 32 == 0 && p.k >= 64 && sk_units < (1ull << 31)) ? knob : 1;   // stream-K forced: 0 = ordered hand-over (the one auto takes), 9 = fix-up kernel
   const unsigned rows = p.n_total ? p.n_total : p.n;   // of the whole job (Problem::n_total)
   const unsigned long long tiles = (unsigned long long)((rows + 127) / 128) * ((p.m + 127) / 128);
   unsigned s;
