@@ -28,13 +28,15 @@ using f64x4 = __attribute__((ext_vector_type(4))) double;
 typedef const __attribute__((address_space(1))) void *gptr_t;
 typedef __attribute__((address_space(3))) void *lptr_t;
 
-template <int WM_, int WN_, int NS_, bool PIPE_ = true>
+template <int WM_, int WN_, int NS_, bool PIPE_ = true, int TM_ = 4, int TP_ = 2, int MIN_WAVES_ = 2>
 struct GeoD {
   static constexpr int WM = WM_, WN = WN_, NS = NS_;
   static constexpr bool PIPE = PIPE_;  // pinned, software-pipelined fragment reads (see the main loop)
-  static constexpr int TM = 4, TP = 2;               // 4 row tiles x (2 pairs of column tiles) of 16
+  static constexpr int TM = TM_, TP = TP_;           // row tiles x pairs of column tiles of 16 (4 x 2: a 64 x 64 wavefront tile)
+  static constexpr int MIN_WAVES = MIN_WAVES_;       // wavefronts per SIMD the kernel is compiled for
   static constexpr int NW = WM * WN, THREADS = NW * 64;
-  static constexpr int BM = WM * 64, BN = WN * 64, BK = 16;
+  static constexpr int WTM = TM * 16, WTN = TP * 32;  // the wavefront's tile
+  static constexpr int BM = WM * WTM, BN = WN * WTN, BK = 16;
   static constexpr int CPR = 8;                      // 16-B chunks per A row (16 doubles)
   static constexpr int A_BYTES = BM * BK * 8, B_BYTES = BK * BN * 8;
   static constexpr int STAGE_BYTES = A_BYTES + B_BYTES, LDS_BYTES = NS * STAGE_BYTES;
@@ -47,7 +49,7 @@ struct GeoD {
 };
 
 template <typename G, bool AT>
-__global__ __launch_bounds__(G::THREADS, 2) void mfma_f64_kernel(  // 2 wavefronts per SIMD: <= 256 VGPRs, so that the
+__global__ __launch_bounds__(G::THREADS, G::MIN_WAVES) void mfma_f64_kernel(  // 2 wavefronts per SIMD: <= 256 VGPRs, so that the
                                                                    // 4-wavefront geometry really fits twice on a CU
     const double *__restrict__ A,
                                                               const double *__restrict__ B,
@@ -140,9 +142,9 @@ __global__ __launch_bounds__(G::THREADS, 2) void mfma_f64_kernel(  // 2 wavefron
   const unsigned a_swz = (lo >> 1) & (CPR - 1);
   // K x N layout: image [k][row]; a lane reads 2 consecutive rows of k-row 2*g4 + p, so row
   // tiles pair up: tile 2q+t holds rows q*32 + 2*i + t
-  const unsigned a_frag_base = AT ? (2 * g4) * (G::BM * 8) + (wm * 64 + 2 * lo) * 8 : (wm * 64 + lo) * (BK * 8);
+  const unsigned a_frag_base = AT ? (2 * g4) * (G::BM * 8) + (wm * G::WTM + 2 * lo) * 8 : (wm * G::WTM + lo) * (BK * 8);
   // B: k = kg*8 + 2*g4 + p; col = wn*64 + pair*32 + 2*lo
-  const unsigned b_frag_base = G::A_BYTES + (2 * g4) * (G::BN * 8) + (wn * 64 + 2 * lo) * 8;
+  const unsigned b_frag_base = G::A_BYTES + (2 * g4) * (G::BN * 8) + (wn * G::WTN + 2 * lo) * 8;
 
   f64x4 acc[TM][TP][2];
 #pragma unroll
@@ -220,7 +222,7 @@ __global__ __launch_bounds__(G::THREADS, 2) void mfma_f64_kernel(  // 2 wavefron
   const unsigned steady = num_tiles - 1;
   for (unsigned t = 0; t < steady; ++t) {
     const unsigned buf = t % NS;
-    if (G::PIPE) {
+    if constexpr (G::PIPE) {
       // Pinned order (round 2).  Written plainly ("read the next group, multiply this one, barrier, refill, ...") the
       // machine scheduler moved BOTH groups' MFMAs behind the barrier: per slab the matrix core then waited for 8
       // fragment reads, the barrier and 6 DMA issues in a row (MfmaUtil 92 %).  Here every fragment is requested 16
@@ -303,14 +305,14 @@ __global__ __launch_bounds__(G::THREADS, 2) void mfma_f64_kernel(  // 2 wavefron
   // epilogue: lane owns 2 consecutive columns of rows g4 + 4*r
 #pragma unroll
   for (int pr = 0; pr < TP; ++pr) {
-    const unsigned ccol = col0 + wn * 64 + pr * 32 + 2 * lo;
+    const unsigned ccol = col0 + wn * G::WTN + pr * 32 + 2 * lo;
     if (ccol >= M) continue;
 #pragma unroll
     for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const unsigned ri = g4 + 4 * r;
-        const unsigned row = row0 + wm * 64 + (AT ? (mi >> 1) * 32 + 2 * ri + (mi & 1) : mi * 16 + ri);
+        const unsigned row = row0 + wm * G::WTM + (AT ? (mi >> 1) * 32 + 2 * ri + (mi & 1) : mi * 16 + ri);
         if (row < N) {
           f64x2 v;
           v[0] = acc[mi][pr][0][r];
@@ -325,6 +327,9 @@ using D0 = GeoD<4, 2, 2>;  // 256 x 128 tile, 8 wavefronts (2 per SIMD), 96 KiB 
 using D1 = GeoD<2, 2, 2>;  // 128 x 128 tile, 4 wavefronts, 64 KiB LDS: two workgroups per CU (small / mid-size shapes)
 using D0R1 = GeoD<4, 2, 2, false>;  // the same tiles with the compiler-placed schedule they first shipped with (f64_variant 2 / 3)
 using D1R1 = GeoD<2, 2, 2, false>;
+// Problems below a round of 128 x 128 tiles (round 3): a 32 x 32 wavefront tile (2 x 1 x 2 accumulators), 64 x 64 per workgroup,
+// 32 KiB of LDS, compiled for four wavefronts per SIMD.  Same fma chain per element as the others: identical bits.
+using DS = GeoD<2, 2, 2, false, 2, 1, 4>;
 
 }  // namespace
 
@@ -341,38 +346,42 @@ static int launch_d(hipStream_t s, const Problem &p) {
     if (int e = ensure_dynamic_lds((const void *)mfma_f64_kernel<G, true>, G::LDS_BYTES, configured_at)) return e;
     hipLaunchKernelGGL((mfma_f64_kernel<G, true>), dim3(tiles_n * tiles_m), dim3(G::THREADS), G::LDS_BYTES, s,
                        (const double *)p.a, (const double *)p.b, (double *)p.c, p.n, p.k, p.m, tiles_n, tiles_m,
-                       band_rows(G::BM, G::BN, G::BM * G::BN <= 128 * 128 ? 2 : 1));
+                       band_rows(G::BM, G::BN, G::BM * G::BN <= 64 * 64 ? 4 : G::BM * G::BN <= 128 * 128 ? 2 : 1));
     return (int)hipGetLastError();
   }
   if (int e = ensure_dynamic_lds((const void *)mfma_f64_kernel<G, false>, G::LDS_BYTES, configured)) return e;
   hipLaunchKernelGGL((mfma_f64_kernel<G, false>), dim3(tiles_n * tiles_m), dim3(G::THREADS), G::LDS_BYTES, s,
                      (const double *)p.a, (const double *)p.b, (double *)p.c, p.n, p.k, p.m, tiles_n, tiles_m,
-                       band_rows(G::BM, G::BN, G::BM * G::BN <= 128 * 128 ? 2 : 1));
+                       band_rows(G::BM, G::BN, G::BM * G::BN <= 64 * 64 ? 4 : G::BM * G::BN <= 128 * 128 ? 2 : 1));
   return (int)hipGetLastError();
 }
 
-int mfma_f64_tile(const Problem &p) {  // 0: 256x128, 1: 128x128
+int mfma_f64_tile(const Problem &p) {  // 0: 256x128, 1: 128x128, 4: 64x64
   const int v = tuning(TUNE_F64_VARIANT);
+  if (v == 4) return 4;
   if (v >= 0) return v & 1;
   // measured (profiles/r02z_f64_pinned_schedule.log): with two workgroups per CU the small tile sustains the same
   // 74.6 TF as the large one at 16384^3; the large one is kept on ties (fewer, larger DMA streams per CU)
-  static const TileCandidate cands[] = {{0, 256, 128, 1, 1.00}, {1, 128, 128, 2, 0.995}};
-  return pick_tile(cands, 2, p.n, p.m);
+  // 64 x 64 (round 3): compiler-placed, four workgroups per CU; efficiency fitted to profiles/r03y_f64_small_tile.txt
+  static const TileCandidate cands[] = {{0, 256, 128, 1, 1.00}, {1, 128, 128, 2, 0.995}, {4, 64, 64, 4, 0.90}};
+  return pick_tile(cands, 3, p.n, p.m);
 }
 
 // One resolver for mm_kernel_name and the launcher: bit 0 = the 128 x 128 tile, bit 1 = the compiler-placed schedule
 // with per-lane 64-bit DMA addresses (f64_variant 2 / 3, and every problem beyond the scalar-base DMA's reach).
 static int resolve(const Problem &p) {
-  if (!mfma_f64_serves(p)) return -1;
+  if (!mfma_f64_serves(p) || tuning(TUNE_F64_VARIANT) > 4) return -1;   // f64_variant: -1 (by shape), 0 .. 4
   // scalar-base DMA: 32-bit byte offsets inside a tile's rows (256 rows x K x 8 B, 16 k-rows x M x 8 B) and K >= BK
   const bool sdma_fits = p.k >= 16 && 256ull * (p.a_transposed ? 1ull : p.k) * 8ull < (1ull << 32) &&
                          16ull * (p.m > p.n ? p.m : p.n) * 8ull < (1ull << 32);
-  return mfma_f64_tile(p) | ((tuning(TUNE_F64_VARIANT) >= 2 || !sdma_fits) ? 2 : 0);
+  const int tile = mfma_f64_tile(p);
+  if (tile == 4) return 4;   // its own (per-lane 64-bit) DMA addresses: no reach limit
+  return tile | ((tuning(TUNE_F64_VARIANT) >= 2 || !sdma_fits) ? 2 : 0);
 }
 
 const char *mfma_f64_name(const Problem &p) {
   static const char *const names[] = {"mfma_f64_256x128x16_w8", "mfma_f64_128x128x16_w4x2", "mfma_f64_256x128x16_w8_compiler_placed",
-                                      "mfma_f64_128x128x16_w4x2_compiler_placed"};
+                                      "mfma_f64_128x128x16_w4x2_compiler_placed", "mfma_f64_64x64x16_w4x4"};
   const int r = resolve(p);
   return r < 0 ? "unsupported" : names[r];
 }
@@ -383,6 +392,7 @@ int launch_mfma_f64(hipStream_t s, const Problem &p) {
     case 1: return launch_d<D1>(s, p);
     case 2: return launch_d<D0R1>(s, p);
     case 3: return launch_d<D1R1>(s, p);
+    case 4: return launch_d<DS>(s, p);
   }
   return kErrNotSupported;
 }

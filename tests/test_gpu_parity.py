@@ -319,12 +319,12 @@ def test_f32_mfma_transpose_detecting_inputs():
                          ids=lambda s: "x".join(map(str, s)))
 def test_f64_schedules_and_tiles_are_bit_identical(shape):
     """f64_variant 0 / 1 = 256x128 / 128x128 tile with the pinned, software-pipelined schedule; 2 / 3 = the same tiles
-    with the compiler-placed schedule of round 1.  Same per-accumulator fma chain in all four, and through the K x N
-    layout of A."""
+    with the compiler-placed schedule of round 1; 4 = the 64x64 geometry of round 3 (32 x 32 per wavefront, for problems
+    below a round of the bigger tiles).  Same per-accumulator fma chain in all five, and through the K x N layout of A."""
     n, k, m = shape
     a, b = _oracle.fill("double", n, k, m)
     out = []
-    for v in (0, 1, 2, 3):
+    for v in (0, 1, 2, 3, 4):
         g.set_tuning("f64_variant", v)
         c, _ = g.matmul_capi(a, b, "double")
         out.append(c)
