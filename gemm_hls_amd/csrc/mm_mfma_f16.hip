@@ -67,6 +67,7 @@ struct GeoHT {
 // A[row = l&31][8 consecutive k at 8*(l>>5)] -- exactly the operand; one barrier per slab, fragments double-buffered.
 using GeoH = GeoHT<4, 2, 2>;   // 256 x 256, 8 wavefronts of 64 x 128 (2 per SIMD)
 using GeoHS = GeoHT<2, 2, 2>;            // 128 x 256, 4 wavefronts of 64 x 128: small / mid-size shapes
+using GeoHXS = GeoHT<2, 2, 1>;           // 64 x 256, 4 wavefronts of 32 x 128: below a round of the 128 x 256 tile (round 3)
 
 // LDS-DMA issued from inline asm.  hipcc waits vmcnt(0) before every ds_read_b64_tr_b16 that
 // follows a __builtin_amdgcn_global_load_lds (the transpose-read builtin carries no alias
@@ -838,11 +839,11 @@ __global__ __launch_bounds__(GeoPP2::THREADS) void mfma_f16_pp2s_kernel(const _F
 
 #undef MM_DMA_PIECE
 
-enum Kind { K_PP16, K_PP32, K_PPK32, K_PPK32_AT, K_SLAB64, K_SLAB64_AT, K_SLAB64_128, K_NONE };
+enum Kind { K_PP16, K_PP32, K_PPK32, K_PPK32_AT, K_SLAB64, K_SLAB64_AT, K_SLAB64_128, K_SLAB64_64, K_NONE };
 const char *const kNames[] = {"mfma_f16_256x256_pingpong_16x16x32", "mfma_f16_256x256_pingpong_32x32x16",
                               "mfma_f16_256x256_pingpong_k32", "mfma_f16_256x256_pingpong_k32_KxN",
                               "mfma_f16_256x256x64_slab64", "mfma_f16_256x256x64_slab64_KxN", "mfma_f16_128x256x64_slab64",
-                              "unsupported"};
+                              "mfma_f16_64x256x64_slab64", "unsupported"};
 
 }  // namespace
 
@@ -862,20 +863,21 @@ static bool ppk32_serves(const Problem &p) {
 }
 static bool pp64_serves(const Problem &p) { return !p.a_transposed && ppk32_serves(p) && p.k % 64 == 0 && p.k >= 256; }
 
-int mfma_f16_tile(const Problem &p) {  // 0: 256x256, 4: 128x256
-  static const TileCandidate cands[] = {{0, 256, 256, 1, 1.00}, {4, 128, 256, 1, 0.80}};
-  return p.a_transposed ? 0 : pick_tile(cands, 2, p.n, p.m);
+int mfma_f16_tile(const Problem &p) {  // 0: 256x256, 4: 128x256, 5: 64x256
+  static const TileCandidate cands[] = {{0, 256, 256, 1, 1.00}, {4, 128, 256, 1, 0.80}, {5, 64, 256, 1, 0.60}};
+  return p.a_transposed ? 0 : pick_tile(cands, 3, p.n, p.m);
 }
 
 // The one place that decides which kernel a (problem, f16_variant knob) pair runs; mm_kernel_name and the launcher
-// both go through it.  f16_variant: -1 the best the shape allows; 0 slab64; 4 slab64 on the 128 x 256 tile;
+// both go through it.  f16_variant: -1 the best the shape allows; 0 slab64; 4 / 5 slab64 on the 128 x 256 / 64 x 256 tile;
 // 11 pingpong_k32; 100 pingpong_32x32x16; 200 pingpong_16x16x32.  A pinned kernel that cannot serve the shape falls
 // through to the next one down (as the default does), so a knob never turns a servable problem into an error.
 static Kind resolve(const Problem &p) {
   if (!mfma_f16_serves(p)) return K_NONE;
   const int v = tuning(TUNE_F16_VARIANT);
-  if (!(v < 0 || v == 0 || v == 4 || v == 11 || v == 100 || v == 200)) return K_NONE;   // lab ids are not in this library
+  if (!(v < 0 || v == 0 || v == 4 || v == 5 || v == 11 || v == 100 || v == 200)) return K_NONE;   // lab ids are not in this library
   if (p.a_transposed) return (v != 0 && ppk32_serves(p)) ? K_PPK32_AT : K_SLAB64_AT;
+  if (v == 5 || (v < 0 && mfma_f16_tile(p) == 5)) return K_SLAB64_64;
   if (v == 4 || (v < 0 && mfma_f16_tile(p) == 4)) return K_SLAB64_128;
   if (v == 0) return K_SLAB64;
   if ((v < 0 || v == 200) && pp64_serves(p)) return K_PP16;   // +7 % over pingpong_32x32x16 (profiles/r03c_*)
@@ -907,6 +909,7 @@ int launch_mfma_f16(hipStream_t s, const Problem &p) {
     case K_SLAB64: return launch_tile(s, p, mfma_f16_kernel<GeoH, false>, GeoH::BM, GeoH::BN, GeoH::THREADS, GeoH::LDS_BYTES, cfg[k]);
     case K_SLAB64_AT: return launch_tile(s, p, mfma_f16_kernel<GeoH, true>, GeoH::BM, GeoH::BN, GeoH::THREADS, GeoH::LDS_BYTES, cfg[k]);
     case K_SLAB64_128: return launch_tile(s, p, mfma_f16_kernel<GeoHS, false>, GeoHS::BM, GeoHS::BN, GeoHS::THREADS, GeoHS::LDS_BYTES, cfg[k]);
+    case K_SLAB64_64: return launch_tile(s, p, mfma_f16_kernel<GeoHXS, false>, GeoHXS::BM, GeoHXS::BN, GeoHXS::THREADS, GeoHXS::LDS_BYTES, cfg[k]);
     default: return kErrNotSupported;
   }
 }

@@ -61,7 +61,8 @@ def test_kernel_name_dispatch_table():
     assert g.kernel_name(g.make_config("double"), 512, 512, 512) == "mfma_f64_64x64x16_w4x4"          # below a round of 128 x 128 tiles
     assert g.kernel_name(g.make_config("double"), 2048, 512, 2048).startswith("mfma_f64_128x128x16")
     assert g.kernel_name(g.make_config("double"), 16384, 16384, 16384) == "mfma_f64_256x128x16_w8"
-    assert g.kernel_name(g.make_config("half"), 512, 512, 512) == "mfma_f16_128x256x64_slab64"     # small problem: 128-row tile
+    assert g.kernel_name(g.make_config("half"), 512, 512, 512) == "mfma_f16_64x256x64_slab64"      # small problem: 64-row tile
+    assert g.kernel_name(g.make_config("half"), 2560, 512, 2560) == "mfma_f16_128x256x64_slab64"
     assert g.kernel_name(g.make_config("half"), 32768, 32768, 32768) == "mfma_f16_256x256_pingpong_16x16x32"
     assert g.kernel_name(g.make_config("half"), 4096, 4128, 4096) == "mfma_f16_256x256_pingpong_k32"   # K % 64 != 0
     assert g.kernel_name(g.make_config("half"), 4096, 4112, 4096) == "mfma_f16_256x256x64_slab64"      # K % 32 != 0

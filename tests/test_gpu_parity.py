@@ -369,13 +369,31 @@ def test_f16_mfma_wide_accumulate_contract(shape):
     assert rel.max() <= 2.0 ** -11 * 1.01      # half an ulp of binary16 relative to the exact value (+f32 noise)
 
 
-@pytest.mark.parametrize("variant", [200, 100, 11, 0, 4])
+@pytest.mark.parametrize("shape", [(1024, 1024, 1024), (513, 1040, 528), (65, 80, 264), (1, 16, 8), (130, 8208, 136)], ids=lambda s: "x".join(map(str, s)))
+def test_f16_slab64_tiles_are_bit_identical(shape):
+    """The slab64 kernel on its three tiles (256 x 256, 128 x 256 and -- round 3, for problems below a round of the others --
+    64 x 256 with 32 x 128 per wavefront): the same MFMAs per output element in the same order, identical bits."""
+    n, k, m = shape
+    rng = np.random.default_rng(n + k)
+    a = rng.uniform(-2, 2, size=(n, k)).astype(np.float16)
+    b = rng.uniform(-2, 2, size=(k, m)).astype(np.float16)
+    out = {}
+    try:
+        for v in (0, 4, 5):
+            g.set_tuning("f16_variant", v)
+            out[v], _ = g.matmul_capi(a, b, "half")
+    finally:
+        g.set_tuning("f16_variant", -1)
+    assert np.array_equal(out[0].view(np.uint16), out[4].view(np.uint16)) and np.array_equal(out[0].view(np.uint16), out[5].view(np.uint16))
+
+
+@pytest.mark.parametrize("variant", [200, 100, 11, 0, 4, 5])
 @pytest.mark.parametrize("shape", [(513, 544, 528), (300, 128, 272), (257, 1056, 520), (1024, 4096, 1024), (129, 160, 264),
                                    (770, 2048, 1288), (300, 256, 272), (513, 576, 528), (260, 320, 264)],
                          ids=lambda s: "x".join(map(str, s)))
 def test_f16_mfma_every_variant(variant, shape):
     """Every kernel of the half family (200: ping-pong on the 16x16x32 instruction, the default; 100: the same on
-    32x32x16; 11: ping-pong with 32-deep A slabs; 0 / 4: one barrier per 64-deep slab, 256 x 256 / 128 x 256 tile)
+    32x32x16; 11: ping-pong with 32-deep A slabs; 0 / 4 / 5: one barrier per 64-deep slab, 256 x 256 / 128 x 256 / 64 x 256 tile)
     against the exact product: same products everywhere, fp32 accumulation, one rounding on store."""
     n, k, m = shape
     rng = np.random.default_rng(n + k)
