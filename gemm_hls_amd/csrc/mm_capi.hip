@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <unordered_set>
 #include <string>
 #include <vector>
 
@@ -199,27 +200,60 @@ struct Event {
 // mm_release_workspace() trims it.
 static hipMemPool_t g_workspace_pool[64] = {};
 static std::mutex g_workspace_mu;
+static int make_pool(int dev, hipMemPool_t &pool) {   // under g_workspace_mu
+  if (pool) return 0;
+  hipMemPoolProps props = {};
+  props.allocType = hipMemAllocationTypePinned;
+  props.handleTypes = hipMemHandleTypeNone;
+  props.location.type = hipMemLocationTypeDevice;
+  props.location.id = dev;
+  hipError_t e = hipMemPoolCreate(&pool, &props);
+  if (e != hipSuccess) { pool = nullptr; return (int)e; }
+  unsigned long long keep = ~0ull;
+  return (int)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+}
 int mm::workspace_pool(int dev, hipMemPool_t *out) {
   std::lock_guard<std::mutex> lock(g_workspace_mu);
   hipMemPool_t &pool = g_workspace_pool[dev & 63];
-  if (!pool) {
-    hipMemPoolProps props = {};
-    props.allocType = hipMemAllocationTypePinned;
-    props.handleTypes = hipMemHandleTypeNone;
-    props.location.type = hipMemLocationTypeDevice;
-    props.location.id = dev;
-    hipError_t e = hipMemPoolCreate(&pool, &props);
-    if (e != hipSuccess) { pool = nullptr; return (int)e; }
-    unsigned long long keep = ~0ull;
-    if ((e = hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep)) != hipSuccess) return (int)e;
-  }
+  if (int rc = make_pool(dev, pool)) return rc;
   *out = pool;
+  return 0;
+}
+
+// Hand-over flags of the stream-K launches (mm_mfma_f32.hip: launch_streamk_ordered).  A flag is "raised" when it holds the
+// launch's EPOCH, a process-wide 64-bit count that no two launches share, so flags never have to be lowered -- provided the
+// memory they live in has never held anything but zeros and epochs.  Hence a second pool of this library's own that
+// serves nothing else, every block of it cleared (stream-ordered) the first time its address is handed out.  That saves
+// the fill kernel and its dependency gap in front of every launch (~10 us: 4 % of a 2560^3 product).  While the stream is
+// being captured into a graph the block is cleared every time: a replay repeats the epoch it was captured with.
+static hipMemPool_t g_flags_pool[64] = {};
+static std::unordered_set<unsigned long long> g_flags_seen[64];
+static std::atomic<unsigned long long> g_flags_epoch{1};
+int mm::flags_alloc(int dev, hipStream_t s, size_t bytes, void **out, unsigned long long *epoch) {
+  std::lock_guard<std::mutex> lock(g_workspace_mu);
+  hipMemPool_t &pool = g_flags_pool[dev & 63];
+  if (int rc = make_pool(dev, pool)) return rc;
+  hipError_t e = hipMallocFromPoolAsync(out, bytes, pool, s);
+  if (e != hipSuccess) return (int)e;
+  hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+  if ((e = hipStreamIsCapturing(s, &capture)) != hipSuccess) { (void)hipFreeAsync(*out, s); return (int)e; }
+  *epoch = g_flags_epoch.fetch_add(1, std::memory_order_relaxed);
+  const bool first_time = g_flags_seen[dev & 63].insert((unsigned long long)(size_t)*out).second;
+  if (first_time || capture != hipStreamCaptureStatusNone) {
+    if ((e = hipMemsetAsync(*out, 0, bytes, s)) != hipSuccess) { (void)hipFreeAsync(*out, s); return (int)e; }
+  }
   return 0;
 }
 int mm::workspace_release(int dev) {
   std::lock_guard<std::mutex> lock(g_workspace_mu);
-  hipMemPool_t pool = g_workspace_pool[dev & 63];
-  return pool ? (int)hipMemPoolTrimTo(pool, 0) : 0;
+  int rc = 0;
+  if (hipMemPool_t pool = g_workspace_pool[dev & 63]) rc = (int)hipMemPoolTrimTo(pool, 0);
+  if (hipMemPool_t pool = g_flags_pool[dev & 63]) {
+    g_flags_seen[dev & 63].clear();   // what comes back from the driver after this is fresh memory again
+    const int rf = (int)hipMemPoolTrimTo(pool, 0);
+    if (!rc) rc = rf;
+  }
+  return rc;
 }
 
 int mm::tuning(mm::Tunable t) {

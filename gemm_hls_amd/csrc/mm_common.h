@@ -95,6 +95,8 @@ size_t mfma_f32_split_workspace_bytes(const Problem &p);
 int mfma_f32_split_tile(const Problem &p, int variant);  // 256 or 128
 int workspace_pool(int device, hipMemPool_t *pool);      // the library-owned, stream-ordered workspace pool of `device` (mm_capi.hip)
 int workspace_release(int device);                       // hands its cached memory back to the driver
+// `bytes` of hand-over flags for one launch on `stream` (free with hipFreeAsync), and the launch's epoch: mm_capi.hip
+int flags_alloc(int device, hipStream_t stream, size_t bytes, void **flags, unsigned long long *epoch);
 int mfma_f32_splitk(const Problem &p, int variant);      // K chunks the fp32 MFMA launcher uses for (problem, resolved variant)
 bool mfma_f32_serves(const Problem &p);
 bool mfma_f64_serves(const Problem &p);

@@ -837,7 +837,7 @@ template <typename G>
 __global__ __launch_bounds__(G::THREADS, G::MIN_WAVES) void mfma_f32_streamk_ordered_kernel(
     const float *__restrict__ A, const float *__restrict__ B, float *__restrict__ C, unsigned N, unsigned K, unsigned M,
     unsigned tiles_n, unsigned tiles_m, unsigned spt, unsigned sr, unsigned sc, unsigned teams_per_xcd, unsigned teams,
-    float *__restrict__ slots, unsigned *__restrict__ flags) {
+    float *__restrict__ slots, unsigned long long *__restrict__ flags, unsigned long long epoch) {
   const unsigned lanes = sr * sc, xcd = blockIdx.x % 8, place = blockIdx.x / 8;
   const unsigned team_in_xcd = place / lanes, lane = place % lanes;
   const unsigned team = team_in_xcd * 8 + xcd, w = team * lanes + lane;   // consecutive teams on consecutive XCDs: fewer teams than places still use all eight
@@ -863,7 +863,7 @@ __global__ __launch_bounds__(G::THREADS, G::MIN_WAVES) void mfma_f32_streamk_ord
       if (threadIdx.x == 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_store(flags + w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(flags + w, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // raised = holds this launch's epoch
       }
     } else {               // the lowest-k segment of a split tile: this one into C, then the others on top in ascending k
       tile_body<G, false>(a, b, C, N, klen, M, K, M, N, M, row0, col0);
@@ -872,7 +872,7 @@ __global__ __launch_bounds__(G::THREADS, G::MIN_WAVES) void mfma_f32_streamk_ord
       while (t_end < teams && sk_range_begin(units, t_end, teams) < u_hi) ++t_end;   // ranges are never empty: teams <= units
       if (threadIdx.x == 0) {
         for (unsigned o = team + 1; o < t_end; ++o)
-          while (__hip_atomic_load(flags + o * lanes + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(8);
+          while (__hip_atomic_load(flags + o * lanes + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(8);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       }
       __syncthreads();     // also: this workgroup's own stores to C are visible to all of its wavefronts
@@ -928,17 +928,18 @@ int launch_streamk_ordered(hipStream_t s, const Problem &p) {
   if (e != hipSuccess) return (int)e;
   hipMemPool_t pool = nullptr;
   if (int rc = workspace_pool(dev, &pool)) return rc;
-  const size_t slot_bytes = (size_t)nwg * G::BM * G::BN * sizeof(float);
-  char *ws = nullptr;
-  if ((e = hipMallocFromPoolAsync((void **)&ws, slot_bytes + nwg * sizeof(unsigned), pool, s)) != hipSuccess) return (int)e;
-  if ((e = hipMemsetAsync(ws + slot_bytes, 0, nwg * sizeof(unsigned), s)) != hipSuccess) { (void)hipFreeAsync(ws, s); return (int)e; }
+  float *slots = nullptr;
+  if ((e = hipMallocFromPoolAsync((void **)&slots, (size_t)nwg * G::BM * G::BN * sizeof(float), pool, s)) != hipSuccess) return (int)e;
+  void *flags = nullptr;
+  unsigned long long epoch = 0;
+  if (int rc = flags_alloc(dev, s, nwg * sizeof(unsigned long long), &flags, &epoch)) { (void)hipFreeAsync(slots, s); return rc; }
   (void)hipGetLastError();
   hipLaunchKernelGGL((mfma_f32_streamk_ordered_kernel<G>), dim3(nwg), dim3(G::THREADS), G::LDS_BYTES, s, (const float *)p.a,
                      (const float *)p.b, (float *)p.c, p.n, p.k, p.m, tiles_n, tiles_m, spt, ts.sr, ts.sc, teams_per_xcd, teams,
-                     (float *)ws, (unsigned *)(ws + slot_bytes));
+                     slots, (unsigned long long *)flags, epoch);
   const int rc = (int)hipGetLastError();
-  const hipError_t f = hipFreeAsync(ws, s);
-  return rc ? rc : (int)f;
+  const hipError_t f1 = hipFreeAsync(flags, s), f2 = hipFreeAsync(slots, s);
+  return rc ? rc : f1 != hipSuccess ? (int)f1 : (int)f2;
 }
 
 // C tile = sum of the scratch slots of the workgroups whose ranges cut it, ascending k.  One workgroup per tile; tiles that

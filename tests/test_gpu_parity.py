@@ -219,6 +219,29 @@ def test_f32_stream_k_for_partial_rounds_is_deterministic_and_accurate(shape, fo
     assert np.max(np.abs(c1 - c_fixup) / scale) < 5e-6
 
 
+def test_f32_stream_k_flags_need_no_clearing_between_launches_and_survive_a_release():
+    """The hand-over flags hold the launch's epoch (a process-wide 64-bit count) in memory that never holds anything else, so
+    a launch does not clear them: back-to-back launches of different shapes reuse the same block, mm_release_workspace hands
+    it back to the driver and the next launch clears its fresh block once.  Same bits throughout."""
+    import torch
+    dev = torch.device("cuda:0")
+    shapes = [(2341, 2304, 2304), (3584, 512, 3584), (2560, 256, 2560)]
+    ops, alone = [], []
+    for i, (n, k, m) in enumerate(shapes):
+        a = torch.empty((n, k), device=dev).uniform_(-3, 10, generator=torch.Generator(device=dev).manual_seed(20 + i))
+        b = torch.empty((k, m), device=dev).uniform_(-3, 10, generator=torch.Generator(device=dev).manual_seed(30 + i))
+        assert g.kernel_name(g.make_config("float"), n, k, m).endswith("streamk")
+        ops.append((a, b))
+        alone.append(g.matmul(a, b).clone())
+    torch.cuda.synchronize()
+    for round_ in range(3):
+        for rep in range(20):
+            for i, (a, b) in enumerate(ops):
+                assert torch.equal(g.matmul(a, b), alone[i]), (round_, rep, shapes[i])
+        torch.cuda.synchronize()
+        g._check(g.lib().mm_release_workspace(0))
+
+
 def test_f32_stream_k_launches_sharing_the_chip_make_progress_and_keep_their_bits():
     """The ordered hand-over waits inside the kernel (a workgroup on flags of workgroups with higher ids).  Two such launches
     on two streams, plus a third stream of whole-tile launches, compete for the same CUs, so neither has all of its
