@@ -238,8 +238,10 @@ int mm::flags_alloc(int dev, hipStream_t s, size_t bytes, void **out, unsigned l
   hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
   if ((e = hipStreamIsCapturing(s, &capture)) != hipSuccess) { (void)hipFreeAsync(*out, s); return (int)e; }
   *epoch = g_flags_epoch.fetch_add(1, std::memory_order_relaxed);
-  const bool first_time = g_flags_seen[dev & 63].insert((unsigned long long)(size_t)*out).second;
-  if (first_time || capture != hipStreamCaptureStatusNone) {
+  // (a block handed out during capture is not recorded: whether the graph ever runs and clears it is not known here)
+  const bool capturing = capture != hipStreamCaptureStatusNone;
+  const bool first_time = !capturing && g_flags_seen[dev & 63].insert((unsigned long long)(size_t)*out).second;
+  if (first_time || capturing) {
     if ((e = hipMemsetAsync(*out, 0, bytes, s)) != hipSuccess) { (void)hipFreeAsync(*out, s); return (int)e; }
   }
   return 0;
@@ -638,8 +640,11 @@ int mm_kernel_info(const mm_config_t *cfg, unsigned n, unsigned k, unsigned m, m
       r.measured_issue_efficiency = 0.967;  // 152.2 TF of 157.3 (profiles/r02z_f32_scalar_base_dma.log)
       break;
     case FAM_MFMA_F64:
-      if (mm::mfma_f64_tile(p) == 1) { r.tile_n = 128; r.tile_m = 128; r.wavefronts = 4; }
-      else { r.tile_n = 256; r.tile_m = 128; r.wavefronts = 8; }
+      switch (mm::mfma_f64_tile(p)) {
+        case 4: r.tile_n = 64; r.tile_m = 64; r.wavefronts = 4; break;
+        case 1: r.tile_n = 128; r.tile_m = 128; r.wavefronts = 4; break;
+        default: r.tile_n = 256; r.tile_m = 128; r.wavefronts = 8; break;
+      }
       r.tile_k = 16;
       r.inst_n = 16; r.inst_m = 16; r.inst_k = 4; r.ops_per_clk_per_cu = 128.0;
       r.measured_issue_efficiency = 0.97;  // pinned schedule + scalar-base DMA: 76.4 TF of 78.6 (profiles/r02z_f64_scalar_base_dma.log)
@@ -647,7 +652,8 @@ int mm_kernel_info(const mm_config_t *cfg, unsigned n, unsigned k, unsigned m, m
     case FAM_MFMA_F16: {
       const std::string name = mm::mfma_f16_name(p);   // geometry read off the resolved kernel's name
       const bool s16 = name.find("16x16x32") != std::string::npos, pp = name.find("pingpong") != std::string::npos;
-      r.tile_n = name.find("128x256") != std::string::npos ? 128 : 256; r.tile_m = 256; r.wavefronts = r.tile_n == 256 ? 8 : 4;
+      r.tile_n = name.find("_64x256") != std::string::npos ? 64 : name.find("128x256") != std::string::npos ? 128 : 256;
+      r.tile_m = 256; r.wavefronts = r.tile_n == 256 ? 8 : 4;
       r.tile_k = pp ? 32 : 64;
       r.inst_n = r.inst_m = s16 ? 16 : 32; r.inst_k = s16 ? 32 : 16; r.ops_per_clk_per_cu = 4096.0;
       // ping-pong schedule: MfmaUtil 91.4 % (16x16x32, profiles/r03g_pmc_f16_32768_16x16x32.json) / 89.7 % (32x32x16) at
