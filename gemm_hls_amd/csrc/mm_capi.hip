@@ -612,6 +612,13 @@ const char *mm_kernel_name(const mm_config_t *cfg, unsigned n, unsigned k, unsig
                                                 "mfma_f32_128x128x32_w4x2_splitk6", "mfma_f32_128x128x32_w4x2_splitk7",
                                                 "mfma_f32_128x128x32_w4x2_splitk8"};
       const int splits = mm::mfma_f32_splitk(p, v);
+      if (v == 64 && splits > 1) {
+        static const char *const small_split_names[] = {nullptr, nullptr, "mfma_f32_64x64x32_w4x2_splitk2", "mfma_f32_64x64x32_w4x2_splitk3",
+                                                        "mfma_f32_64x64x32_w4x2_splitk4", "mfma_f32_64x64x32_w4x2_splitk5",
+                                                        "mfma_f32_64x64x32_w4x2_splitk6", "mfma_f32_64x64x32_w4x2_splitk7",
+                                                        "mfma_f32_64x64x32_w4x2_splitk8"};
+        return small_split_names[splits];
+      }
       if (splits == 0) return "mfma_f32_128x128x32_w4x2_streamk";
       if (splits == 9) return "mfma_f32_128x128x32_w4x2_streamk_fixup";
       return splits > 1 ? split_names[splits] : mm::mfma_f32_name(v);

@@ -595,10 +595,20 @@ using Small = SmallT<4>;
 template <typename G>
 __global__ __launch_bounds__(G::THREADS, G::PER_CU) void mfma_f32_small_kernel(
     const float *__restrict__ A, const float *__restrict__ B, float *__restrict__ C, unsigned N, unsigned K, unsigned M,
-    unsigned tiles_n, unsigned tiles_m, unsigned kBand) {
+    unsigned tiles_n, unsigned tiles_m, unsigned kBand, unsigned kChunk, float *__restrict__ partials) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const unsigned nwg = tiles_n * tiles_m;
-  const unsigned lin = xcd_remap(blockIdx.x, nwg);
+  const unsigned lda = K;
+  unsigned bid = blockIdx.x;
+  if (kChunk) {   // split-K (few tiles, long K), as in mfma_f32_kernel: copy `split` of the tile grid multiplies its k range into its own plane
+    const unsigned split = bid / nwg, kbeg = split * kChunk;
+    bid -= split * nwg;
+    A += kbeg;
+    B += (size_t)kbeg * M;
+    C = partials + (size_t)split * N * M;
+    K = min(kChunk, K - kbeg);
+  }
+  const unsigned lin = xcd_remap(bid, nwg);
   const unsigned band = lin / (kBand * tiles_m), within = lin % (kBand * tiles_m);
   const unsigned rows_in_band = min(kBand, tiles_n - band * kBand);
   const unsigned row0 = (band * kBand + within % rows_in_band) * G::BM, col0 = (within / rows_in_band) * G::BN;
@@ -616,7 +626,7 @@ __global__ __launch_bounds__(G::THREADS, G::PER_CU) void mfma_f32_small_kernel(
     const unsigned slot = (wave + 4 * i) * 64 + lane;
     const unsigned row = slot >> 3, pc = slot & 7u;
     a_k[i] = (pc ^ ((row >> 1) & 7u)) * 4;
-    a_row_off[i] = (size_t)min(row0 + row, N - 1) * K;
+    a_row_off[i] = (size_t)min(row0 + row, N - 1) * lda;
     const unsigned k = slot >> 4, pcb = slot & 15u;
     b_k[i] = k;
     b_col[i] = min(col0 + (pcb ^ ((k & 4u) << 1)) * 4, M - 4);
@@ -640,7 +650,7 @@ __global__ __launch_bounds__(G::THREADS, G::PER_CU) void mfma_f32_small_kernel(
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const unsigned slot = (wave + 4 * i) * 64 + lane;
-    voa[i] = (min(row0 + (slot >> 3), N - 1) - row0) * K * 4u + a_k[i] * 4u;
+    voa[i] = (min(row0 + (slot >> 3), N - 1) - row0) * lda * 4u + a_k[i] * 4u;
     vob[i] = b_k[i] * M * 4u + (b_col[i] - col0) * 4u;
   }
   const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
@@ -648,7 +658,7 @@ __global__ __launch_bounds__(G::THREADS, G::PER_CU) void mfma_f32_small_kernel(
     const unsigned kc = min(k0, K - G::BK);
     const bool is_a = i < 2;
     const int j = is_a ? i : i - 2;
-    unsigned long long base = is_a ? (unsigned long long)(A + (size_t)row0 * K + kc) : (unsigned long long)(B + (size_t)kc * M + col0);
+    unsigned long long base = is_a ? (unsigned long long)(A + (size_t)row0 * lda + kc) : (unsigned long long)(B + (size_t)kc * M + col0);
     const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)base), bhi = __builtin_amdgcn_readfirstlane((unsigned)(base >> 32));
     base = ((unsigned long long)bhi << 32) | blo;
     const unsigned la = lds_base + buf * G::STAGE_BYTES + (is_a ? 0 : G::A_BYTES) + (wave + 4 * j) * 1024;
@@ -761,16 +771,7 @@ __global__ __launch_bounds__(G::THREADS, G::PER_CU) void mfma_f32_small_kernel(
   write_tile(flushed);
 }
 
-template <typename G = Small>
-int launch_small(hipStream_t s, const Problem &p) {
-  const unsigned tiles_n = (p.n + G::BM - 1) / G::BM, tiles_m = (p.m + G::BN - 1) / G::BN;
-  static unsigned long long configured = 0;
-  if (int e = ensure_dynamic_lds((const void *)mfma_f32_small_kernel<G>, G::LDS_BYTES, configured)) return e;
-  (void)hipGetLastError();
-  hipLaunchKernelGGL((mfma_f32_small_kernel<G>), dim3(tiles_n * tiles_m), dim3(G::THREADS), G::LDS_BYTES, s, (const float *)p.a,
-                     (const float *)p.b, (float *)p.c, p.n, p.k, p.m, tiles_n, tiles_m, band_rows(G::BM, G::BN, G::PER_CU));
-  return (int)hipGetLastError();
-}
+// (launch_small: after the split-K reduce kernel, which it shares with launch_geo)
 
 // ---- stream-K (round 3): problems of a few partial rounds of tiles ------------------------------------------------
 // A launch runs in whole rounds of resident workgroups, so 2560^3 (400 tiles of 128 x 128 for 512 slots) or 3072^3 (576
@@ -1115,6 +1116,41 @@ static bool streamk_wins(const Problem &p) {
   return sk < 0.99 * whole;
 }
 
+template <typename G>
+static int launch_small(hipStream_t s, const Problem &p, unsigned splits) {
+  const unsigned tiles_n = (p.n + G::BM - 1) / G::BM, tiles_m = (p.m + G::BN - 1) / G::BN;
+  static unsigned long long configured = 0;
+  if (int e = ensure_dynamic_lds((const void *)mfma_f32_small_kernel<G>, G::LDS_BYTES, configured)) return e;
+  (void)hipGetLastError();
+  const unsigned kband = band_rows(G::BM, G::BN, G::PER_CU);
+  if (splits <= 1) {
+    hipLaunchKernelGGL((mfma_f32_small_kernel<G>), dim3(tiles_n * tiles_m), dim3(G::THREADS), G::LDS_BYTES, s, (const float *)p.a,
+                       (const float *)p.b, (float *)p.c, p.n, p.k, p.m, tiles_n, tiles_m, kband, 0u, (float *)nullptr);
+    return (int)hipGetLastError();
+  }
+  // split-K, exactly as launch_geo: planes of partial sums from the library's pool, then the ordered reduction
+  const unsigned chunk = ((p.k + splits - 1) / splits + 31u) & ~31u;
+  if ((unsigned long long)(splits - 1) * chunk >= p.k) return kErrNotSupported;   // (the rule never asks for an empty chunk)
+  const size_t plane = (size_t)p.n * p.m;
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return (int)e;
+  hipMemPool_t pool = nullptr;
+  if (int rc = workspace_pool(dev, &pool)) return rc;
+  float *ws = nullptr;
+  if ((e = hipMallocFromPoolAsync((void **)&ws, plane * splits * sizeof(float), pool, s)) != hipSuccess) return (int)e;
+  hipLaunchKernelGGL((mfma_f32_small_kernel<G>), dim3(tiles_n * tiles_m * splits), dim3(G::THREADS), G::LDS_BYTES, s, (const float *)p.a,
+                     (const float *)p.b, (float *)p.c, p.n, p.k, p.m, tiles_n, tiles_m, kband, chunk, ws);
+  int rc = (int)hipGetLastError();
+  if (rc == 0) {
+    const size_t quads = plane / 4;   // M % 4 == 0
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, s, ws, (float *)p.c, quads, splits);
+    rc = (int)hipGetLastError();
+  }
+  const hipError_t f = hipFreeAsync(ws, s);
+  return rc ? rc : (int)f;
+}
+
 // K chunks of the shape-adaptive split-K rule for `tiles` tiles of 128 x 128 (mfma_f32_splitk): when the tiles leave a quarter
 // or more of the CUs without a workgroup, as many copies of the tile grid as fit the 512 places, at most 8, chunks >= 256 k
 static unsigned auto_split_chunks(unsigned long long tiles, unsigned k) {
@@ -1135,16 +1171,30 @@ static bool small_fits(const Problem &p) {
 //              more than 512 tiles never (a second round: the 128 x 128 tile's half bytes per flop win);
 //   128 x 128: 5 + slabs x 1.79 (one workgroup per CU) or x 3.49 (two); a split adds the partial planes' round trip and
 //              the reduce kernel: + 13.5.
-// 1024^3 105 vs 75 TF, 1024 x 512 x 1024 89 vs 40, 768^3 56 vs 34, 512^3 23 vs 12, 1280^3 98 vs 91; split-K keeps the long-K
-// shapes with few tiles (512 x 4096 x 512: 53 vs 31) and 1536^3 (576 tiles of 64 x 64).  Decided on the whole job
+// 1024^3 105 vs 75 TF, 1024 x 512 x 1024 89 vs 40, 768^3 56 vs 34, 512^3 23 vs 12, 1280^3 98 vs 91; the 128 x 128 geometry with
+// its split keeps 1536^3 (576 tiles of 64 x 64); few tiles and a long K split on this geometry too (small_split_chunks).  Decided on the whole job
 // (Problem::n_total), like the split itself, so row slabs keep the bits of the one-launch result.
+// The 64 x 64 geometry splits K too when its tiles leave half the CUs or more without a workgroup (<= 128 tiles): as many
+// copies of the tile grid as fit one workgroup per CU, at most 8, chunks of at least 512 k, and only if the model says the
+// second kernel pays (+ 13.5 us).  512 x 4096 x 512: 31 -> 81 TF (split-K on the 128 x 128 geometry: 53), 256 x 8192 x 256: 8 -> 40 (16).
+static unsigned small_split_chunks(const Problem &p) {
+  const unsigned rows = p.n_total ? p.n_total : p.n;
+  const unsigned long long t64 = (unsigned long long)((rows + 63) / 64) * ((p.m + 63) / 64);
+  if (tuning(TUNE_F32_SPLITK) == 1 || t64 > 128) return 1;
+  unsigned s = (unsigned)(256 / t64);
+  if (s > 8) s = 8;
+  while (s > 1 && p.k / s < 512) --s;
+  const double slabs = (p.k + 31) / 32;
+  return (s > 1 && 13.5 + (slabs / s) * 0.52 < slabs * 0.52) ? s : 1;
+}
 static bool small_wins(const Problem &p) {
   if (!small_fits(p) || p.k < 32) return false;
   const unsigned rows = p.n_total ? p.n_total : p.n;
   const unsigned long long t64 = (unsigned long long)((rows + 63) / 64) * ((p.m + 63) / 64), t128 = (unsigned long long)((rows + 127) / 128) * ((p.m + 127) / 128);
   if (t64 > 512) return false;
   const double slabs = (p.k + 31) / 32;
-  const double t_small = 3.5 + slabs * (t64 <= 256 ? 0.52 : 0.90);
+  const unsigned ss = small_split_chunks(p);
+  const double t_small = 3.5 + (ss > 1 ? 13.5 : 0.0) + (slabs / ss) * (t64 * ss <= 256 ? 0.52 : 0.90);
   const unsigned s = tuning(TUNE_F32_SPLITK) == 1 ? 1 : auto_split_chunks(t128, p.k);
   const double t_128 = (s > 1 ? 18.5 : 5.0) + (slabs / s) * (t128 * s <= 256 ? 1.79 : 3.49);
   return t_small < t_128;
@@ -1235,6 +1285,12 @@ int mfma_f32_resolve(const Problem &p, int variant) {
 // depend on the slab, and with them a row's summation order.
 int mfma_f32_splitk(const Problem &p, int variant) {
   if (p.a_transposed) return transposes_first(p, tuning(TUNE_F32_VARIANT)) ? mfma_f32_splitk(as_row_major(p), variant) : 1;
+  if (variant == 64) {   // the 64 x 64 geometry: its own rule under the shape-adaptive pick, 2..8 forced by the knob
+    const int forced = tuning(TUNE_F32_SPLITK);
+    unsigned s = forced >= 2 && forced <= 8 ? (unsigned)forced : tuning(TUNE_F32_VARIANT) >= 0 ? 1u : small_split_chunks(p);
+    while (s > 1 && p.k / s < 64) --s;
+    return (int)s;
+  }
   if (variant != 35) return 1;
   const int knob = tuning(TUNE_F32_SPLITK);
   const unsigned long long sk_units = (unsigned long long)((p.n + 127) / 128) * ((p.m + 127) / 128) * (p.k / 32);   // the kernels count units in 32 bits
@@ -1301,7 +1357,7 @@ int launch_mfma_f32(hipStream_t s, const Problem &p, int variant) {
       if (splits == 9) return sdma_fits(p, 32) ? launch_streamk<T128x128>(s, p) : launch_streamk<T128x128v>(s, p);
       return sdma_fits(p, 32) ? launch_geo<T128x128>(s, p, (unsigned)splits) : launch_geo<T128x128v>(s, p, (unsigned)splits);
     }
-    case 64: return launch_small<Small>(s, p);
+    case 64: return launch_small<Small>(s, p, (unsigned)mfma_f32_splitk(p, v));
     case 0: return launch_geo<X128x256x32_2lvl>(s, p);
     case 3: return launch_geo<X256x256_single>(s, p);
   }

@@ -144,6 +144,40 @@ def test_f32_64x64_geometry_edges(shape):
     assert np.max(np.abs(c64 - exact) / scale) < 2e-6
 
 
+@pytest.mark.parametrize("shape,splitk,expect", [((512, 4096, 512), -1, "mfma_f32_64x64x32_w4x2_splitk4"), ((256, 8192, 256), -1, "mfma_f32_64x64x32_w4x2_splitk8"),
+                                                 ((300, 2048, 272), 3, "mfma_f32_64x64x32_w4x2_splitk3"), ((129, 4104, 132), 8, "mfma_f32_64x64x32_w4x2_splitk8"),
+                                                 ((70, 200, 68), 2, "mfma_f32_64x64x32_w4x2_splitk2")],
+                         ids=lambda v: "x".join(map(str, v)) if isinstance(v, tuple) else str(v))
+def test_f32_64x64_geometry_splits_k_for_few_tiles_and_long_k(shape, splitk, expect):
+    """Few tiles of 64 x 64 and a long K (512 x 4096 x 512: 64 tiles for 256 CUs): the small geometry runs up to 8 copies of its
+    tile grid on K chunks of >= 512 and the ordered reduce kernel adds the planes, when its time model says the second kernel
+    pays (auto cases) or when forced (f32_variant 64 + f32_splitk 2..8; chunks that end mid-slab included).  Deterministic;
+    close to the unsplit kernel, not the same summation order."""
+    n, k, m = shape
+    rng = np.random.default_rng(k + n)
+    a = rng.uniform(-3, 10, size=(n, k)).astype(np.float32)
+    b = rng.uniform(-3, 10, size=(k, m)).astype(np.float32)
+    exact = a.astype(np.float64) @ b.astype(np.float64)
+    scale = np.abs(a.astype(np.float64)) @ np.abs(b.astype(np.float64))
+    try:
+        if splitk > 1:
+            g.set_tuning("f32_variant", 64)
+            g.set_tuning("f32_splitk", splitk)
+        name = g.kernel_name(g.make_config("float"), n, k, m)
+        c1, _ = g.matmul_capi(a, b)
+        c2, _ = g.matmul_capi(a, b)
+        g.set_tuning("f32_variant", 64)
+        g.set_tuning("f32_splitk", 1)
+        c_one, _ = g.matmul_capi(a, b)
+    finally:
+        g.set_tuning("f32_splitk", -1)
+        g.set_tuning("f32_variant", -1)
+    assert name == expect, name
+    assert np.array_equal(c1, c2)
+    assert np.max(np.abs(c1 - exact) / scale) < 2e-6
+    assert np.max(np.abs(c1 - c_one) / scale) < 5e-6
+
+
 @pytest.mark.parametrize("shape,splitk", [((512, 4096, 512), -1), ((1024, 1024, 1024), 2), ((300, 2048, 272), 8), ((129, 4104, 132), 3),
                                           ((257, 4104, 260), -1), ((1536, 1536, 1536), -1), ((640, 520, 384), 2), ((1024, 1024, 1024), 4)],
                          ids=lambda v: "x".join(map(str, v)) if isinstance(v, tuple) else f"splitk{v}")
