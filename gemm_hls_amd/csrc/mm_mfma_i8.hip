@@ -35,10 +35,12 @@ using i32x16 = __attribute__((ext_vector_type(16))) int;
 typedef int v2i __attribute__((vector_size(8)));
 typedef __attribute__((address_space(3))) void *lptr_t;
 
-struct GeoI8 {
-  static constexpr int WM = 4, WN = 2, NS = 2, TM = 2, TN = 4;
+template <int WM_, int WN_, int TM_>
+struct GeoI8T {
+  static constexpr int WM = WM_, WN = WN_, NS = 2, TM = TM_, TN = 4;
   static constexpr int NW = WM * WN, THREADS = NW * 64;
-  static constexpr int BM = 256, BN = 256, BK = 128;           // BK in elements == bytes
+  static constexpr int BM = WM * TM * 32, BN = WN * TN * 32, BK = 128;   // BK in elements == bytes
+  static_assert(BN == 256, "B swizzle / chunk math assumes 256-column slabs");
   static constexpr int CPR = 8;                                // 16-B chunks per A row
   static constexpr int BROW = BN, BCH = BROW / 16;             // B k-row bytes / chunks
   static constexpr int A_BYTES = BM * BK, B_BYTES = BK * BROW;
@@ -47,6 +49,8 @@ struct GeoI8 {
   static constexpr int LA = NA / NW, LB = NB / NW;
   static constexpr int KS = BK / 32;                           // MFMA k-steps per slab
 };
+using GeoI8 = GeoI8T<4, 2, 2>;    // 256 x 256, 8 wavefronts of 64 x 128
+using GeoI8S = GeoI8T<2, 2, 1>;   // 64 x 256, 4 wavefronts of 32 x 128: problems below a round of the 256 x 256 tile (round 3; row-major A only)
 
 // asm LDS-DMA (see mm_mfma_f16.hip: transpose-read builtins make hipcc drain builtin DMAs)
 __device__ __forceinline__ void dma16(const void *gsrc, unsigned lds_byte_addr) {
@@ -68,13 +72,12 @@ __device__ __forceinline__ i32x4 join(v2i lo, v2i hi) {
   return r;
 }
 
-template <bool AT>
-__global__ __launch_bounds__(GeoI8::THREADS) void mfma_i8_kernel(const signed char *__restrict__ A,
+template <typename G, bool AT>
+__global__ __launch_bounds__(G::THREADS) void mfma_i8_kernel(const signed char *__restrict__ A,
                                                                  const signed char *__restrict__ B,
                                                                  signed char *__restrict__ C, unsigned N, unsigned K,
                                                                  unsigned M, unsigned tiles_n, unsigned tiles_m,
                                                                  unsigned kBand) {
-  using G = GeoI8;
   constexpr int TM = G::TM, TN = G::TN, BK = G::BK, NS = G::NS, CPR = G::CPR;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const unsigned lane = threadIdx.x & 63u;
@@ -734,10 +737,10 @@ __global__ __launch_bounds__(GeoI8PP2::THREADS) void mfma_i8_pp2s_kernel(const s
 }
 #undef MM_DMA_PIECE
 
-enum Kind { K_PP16, K_PP32, K_PPK64, K_PPK64_AT, K_SLAB128, K_SLAB128_AT, K_NONE };
+enum Kind { K_PP16, K_PP32, K_PPK64, K_PPK64_AT, K_SLAB128, K_SLAB128_AT, K_SLAB128_64, K_NONE };
 const char *const kNames[] = {"mfma_i8_256x256_pingpong_16x16x64", "mfma_i8_256x256_pingpong_32x32x32", "mfma_i8_256x256_pingpong_k64",
                               "mfma_i8_256x256_pingpong_k64_KxN", "mfma_i8_256x256x128_slab128", "mfma_i8_256x256x128_slab128_KxN",
-                              "unsupported"};
+                              "mfma_i8_64x256x128_slab128", "unsupported"};
 
 }  // namespace
 
@@ -756,13 +759,22 @@ static bool ppk64_serves(const Problem &p) {
 }
 static bool pp128_serves(const Problem &p) { return !p.a_transposed && ppk64_serves(p) && p.k % 128 == 0 && p.k >= 512; }
 
-// i8_variant: -1 the best the shape allows; 0 slab128; 10 pingpong_k64; 100 pingpong_32x32x32; 200 pingpong_16x16x64
-// (one resolver for mm_kernel_name and the launcher; a pinned kernel that cannot serve the shape falls through).
+// Below a round of 256 x 256 tiles the slab128 kernel's 64 x 256 tile gives four times the workgroups (1024^3: 64 instead
+// of 16 for 256 CUs); efficiency relative to the ping-pong kernel fitted to profiles/r03y_i8_small_tile.txt.
+static int mfma_i8_tile(const Problem &p) {  // 0: 256x256, 5: 64x256
+  static const TileCandidate cands[] = {{0, 256, 256, 1, 1.00}, {5, 64, 256, 1, 0.45}};
+  return p.a_transposed ? 0 : pick_tile(cands, 2, p.n, p.m);
+}
+
+// i8_variant: -1 the best the shape allows; 0 slab128; 5 slab128 on the 64 x 256 tile; 10 pingpong_k64; 100 pingpong_32x32x32;
+// 200 pingpong_16x16x64 (one resolver for mm_kernel_name and the launcher; a pinned kernel that cannot serve the shape
+// falls through).
 static Kind resolve(const Problem &p) {
   if (!mfma_i8_serves(p)) return K_NONE;
   const int v = tuning(TUNE_I8_VARIANT);
-  if (!(v < 0 || v == 0 || v == 10 || v == 100 || v == 200)) return K_NONE;   // lab ids are not in this library
+  if (!(v < 0 || v == 0 || v == 5 || v == 10 || v == 100 || v == 200)) return K_NONE;   // lab ids are not in this library
   if (p.a_transposed) return (v != 0 && ppk64_serves(p)) ? K_PPK64_AT : K_SLAB128_AT;
+  if (v == 5 || (v < 0 && mfma_i8_tile(p) == 5)) return K_SLAB128_64;
   if (v == 0) return K_SLAB128;
   if ((v < 0 || v == 200) && pp128_serves(p)) return K_PP16;  // +7.6 % over pingpong_32x32x32 (profiles/r03e_*)
   if (v == 100 && pp128_serves(p)) return K_PP32;
@@ -773,11 +785,12 @@ static Kind resolve(const Problem &p) {
 const char *mfma_i8_name(const Problem &p) { return kNames[resolve(p)]; }
 
 template <typename Kern>
-static int launch_tile(hipStream_t s, const Problem &p, Kern kern, unsigned threads, int lds, unsigned long long &configured) {
-  const unsigned tiles_n = (p.n + 255) / 256, tiles_m = (p.m + 255) / 256;
+static int launch_tile(hipStream_t s, const Problem &p, Kern kern, unsigned threads, int lds, unsigned long long &configured,
+                       unsigned bm = 256) {
+  const unsigned tiles_n = (p.n + bm - 1) / bm, tiles_m = (p.m + 255) / 256;
   if (int e = ensure_dynamic_lds((const void *)kern, lds, configured)) return e;
   hipLaunchKernelGGL(kern, dim3(tiles_n * tiles_m), dim3(threads), lds, s, (const signed char *)p.a, (const signed char *)p.b,
-                     (signed char *)p.c, p.n, p.k, p.m, tiles_n, tiles_m, band_rows());
+                     (signed char *)p.c, p.n, p.k, p.m, tiles_n, tiles_m, band_rows(bm, 256, 1));
   return (int)hipGetLastError();
 }
 
@@ -789,8 +802,9 @@ int launch_mfma_i8(hipStream_t s, const Problem &p) {
     case K_PP32: return launch_tile(s, p, mfma_i8_pp2_kernel, GeoI8PP2::THREADS, GeoI8PP2::LDS_BYTES, cfg[k]);
     case K_PPK64: return launch_tile(s, p, mfma_i8_pp_kernel<false>, GeoI8PP::THREADS, GeoI8PP::LDS_BYTES, cfg[k]);
     case K_PPK64_AT: return launch_tile(s, p, mfma_i8_pp_kernel<true>, GeoI8PP::THREADS, GeoI8PP::LDS_BYTES, cfg[k]);
-    case K_SLAB128: return launch_tile(s, p, mfma_i8_kernel<false>, GeoI8::THREADS, GeoI8::LDS_BYTES, cfg[k]);
-    case K_SLAB128_AT: return launch_tile(s, p, mfma_i8_kernel<true>, GeoI8::THREADS, GeoI8::LDS_BYTES, cfg[k]);
+    case K_SLAB128: return launch_tile(s, p, mfma_i8_kernel<GeoI8, false>, GeoI8::THREADS, GeoI8::LDS_BYTES, cfg[k]);
+    case K_SLAB128_AT: return launch_tile(s, p, mfma_i8_kernel<GeoI8, true>, GeoI8::THREADS, GeoI8::LDS_BYTES, cfg[k]);
+    case K_SLAB128_64: return launch_tile(s, p, mfma_i8_kernel<GeoI8S, false>, GeoI8S::THREADS, GeoI8S::LDS_BYTES, cfg[k], GeoI8S::BM);
     default: return kErrNotSupported;
   }
 }

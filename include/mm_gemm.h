@@ -209,7 +209,7 @@ int mm_kernel_info(const mm_config_t *cfg, unsigned size_n, unsigned size_k, uns
 /* Tuning knobs for sweeps ("f32_variant", "f64_variant", "f16_variant", "i8_variant", "valu_variant", "split_variant",
  * "band_rows", "f32_splitk"; -1 = the library's own choice).  Kernel ids of this library: f32_variant 33 / 8 / 35 / 64 (the
  * geometries of the shape-adaptive pick) and 0 / 3 (cross-checks); f16_variant 200 / 100 / 11 / 0 / 4 / 5; i8_variant 200 /
- * 100 / 10 / 0; f64_variant 0-4 (4: the 64 x 64 geometry for small problems); f32_splitk 0 stream-K (ordered hand-over inside the launch), 1 whole tiles, 2-8 K chunks, 9 stream-K with the fix-up kernel.  Any other id is refused: the retired
+ * 100 / 10 / 5 / 0; f64_variant 0-4 (4: the 64 x 64 geometry for small problems); f32_splitk 0 stream-K (ordered hand-over inside the launch), 1 whole tiles, 2-8 K chunks, 9 stream-K with the fix-up kernel.  Any other id is refused: the retired
  * schedules and the work-skipping ablations of the measurement history exist only in the lab build
  * (tools/lab/libmm_gemm_amd_lab.so, where "ablations" = 1 unlocks the latter).  Each knob is initialised ONCE from its
  * environment variable (MM_F32_VARIANT, ...) and changed only through this call afterwards; the launch path never reads

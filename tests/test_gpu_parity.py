@@ -506,7 +506,7 @@ def test_i8_mfma_is_bit_exact_mod_256(dtype, shape):
 
 
 @pytest.mark.parametrize("dtype", ["int8_t", "uint8_t"])
-@pytest.mark.parametrize("variant", [-1, 0, 10, 100, 200])
+@pytest.mark.parametrize("variant", [-1, 0, 5, 10, 100, 200])
 @pytest.mark.parametrize("shape", [(513, 576, 528), (300, 4160, 272), (257, 256, 1040), (1024, 1024, 1024), (1, 320, 16),
                                    (513, 640, 528), (300, 4224, 272), (260, 512, 1040)],
                          ids=lambda s: "x".join(map(str, s)))
