@@ -55,9 +55,10 @@ def test_kernel_name_dispatch_table():
     assert g.kernel_name(g.make_config("float", "Add", "Min"), 64, 63, 64) == "ordered"      # K % 4 != 0
     assert g.kernel_name(g.make_config("int", "And", "Add"), 64, 64, 64) == "ordered"        # And map
     # every family names the kernel its launcher resolves to (one resolver per family, shared with the launch path)
-    assert g.kernel_name(g.make_config("uint8_t"), 512, 512, 512) == "mfma_i8_256x256_pingpong_16x16x64"
-    assert g.kernel_name(g.make_config("uint8_t"), 512, 576, 512) == "mfma_i8_256x256_pingpong_k64"
-    assert g.kernel_name(g.make_config("uint8_t"), 512, 96, 512) == "mfma_i8_256x256x128_slab128"
+    assert g.kernel_name(g.make_config("uint8_t"), 512, 512, 512) == "mfma_i8_64x256x128_slab128"           # small problem: 64-row tile
+    assert g.kernel_name(g.make_config("uint8_t"), 4096, 512, 4096) == "mfma_i8_256x256_pingpong_16x16x64"
+    assert g.kernel_name(g.make_config("uint8_t"), 4096, 576, 4096) == "mfma_i8_256x256_pingpong_k64"
+    assert g.kernel_name(g.make_config("uint8_t"), 4096, 96, 4096) == "mfma_i8_256x256x128_slab128"
     assert g.kernel_name(g.make_config("double"), 512, 512, 512) == "mfma_f64_64x64x16_w4x4"          # below a round of 128 x 128 tiles
     assert g.kernel_name(g.make_config("double"), 2048, 512, 2048).startswith("mfma_f64_128x128x16")
     assert g.kernel_name(g.make_config("double"), 16384, 16384, 16384) == "mfma_f64_256x128x16_w8"
