@@ -671,7 +671,7 @@ int mm_kernel_info(const mm_config_t *cfg, unsigned n, unsigned k, unsigned m, m
     case FAM_MFMA_I8: {
       const std::string name = mm::mfma_i8_name(p);
       const bool s16 = name.find("16x16x64") != std::string::npos, pp = name.find("pingpong") != std::string::npos;
-      r.tile_n = 256; r.tile_m = 256; r.wavefronts = 8;
+      r.tile_n = name.find("_64x256") != std::string::npos ? 64 : 256; r.tile_m = 256; r.wavefronts = r.tile_n == 256 ? 8 : 4;
       r.tile_k = pp ? 64 : 128;
       r.inst_n = r.inst_m = s16 ? 16 : 32; r.inst_k = s16 ? 64 : 32; r.ops_per_clk_per_cu = 8192.0;
       r.measured_issue_efficiency = pp ? 0.92 : 0.68;  // profiles/r02i_pmc_i8_32768.json / r01_pmc_i8.json

@@ -141,6 +141,6 @@ def test_f32_variant_ids_of_the_product():
 def test_kernel_info_binding():
     info = g.kernel_info(g.make_config("float"), 16384, 16384, 16384)
     assert (info.tile_n, info.tile_m, info.tile_k, info.wavefronts) == (128, 256, 16, 4)   # two such workgroups per CU
-    small = [g.kernel_info(g.make_config(t), 512, 512, 512) for t in ("float", "double", "half")]   # the small-problem geometries (round 3)
-    assert [(i.tile_n, i.tile_m, i.tile_k, i.wavefronts) for i in small] == [(64, 64, 32, 4), (64, 64, 16, 4), (64, 256, 64, 4)]
+    small = [g.kernel_info(g.make_config(t), 512, 512, 512) for t in ("float", "double", "half", "uint8_t")]   # the small-problem geometries (round 3)
+    assert [(i.tile_n, i.tile_m, i.tile_k, i.wavefronts) for i in small] == [(64, 64, 32, 4), (64, 64, 16, 4), (64, 256, 64, 4), (64, 256, 128, 4)]
     assert info.compute_units == 256 and info.max_clock_mhz == 2400.0
