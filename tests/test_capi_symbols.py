@@ -144,3 +144,56 @@ def test_kernel_info_binding():
     small = [g.kernel_info(g.make_config(t), 512, 512, 512) for t in ("float", "double", "half", "uint8_t")]   # the small-problem geometries (round 3)
     assert [(i.tile_n, i.tile_m, i.tile_k, i.wavefronts) for i in small] == [(64, 64, 32, 4), (64, 64, 16, 4), (64, 256, 64, 4), (64, 256, 128, 4)]
     assert info.compute_units == 256 and info.max_clock_mhz == 2400.0
+
+
+DISPATCH_TABLE = [
+    # the shape-adaptive rules as measured in round 3 (profiles/r03w_*, r03x_*, r03y_*, r03z_f32_sizes_back_to_back_vs_library.txt):
+    # a change here is a change of a measured decision and wants a new measurement, not just a new expectation
+    ("float", (512, 512, 512), False, "mfma_f32_64x64x32_w4x2_flush4096"),          # below a round of 128 x 128 tiles: the 64 x 64 geometry
+    ("float", (1024, 1024, 1024), False, "mfma_f32_64x64x32_w4x2_flush4096"),
+    ("float", (1280, 1280, 1280), False, "mfma_f32_64x64x32_w4x2_flush4096"),
+    ("float", (1024, 512, 1024), False, "mfma_f32_64x64x32_w4x2_flush4096"),
+    ("float", (512, 4096, 512), False, "mfma_f32_64x64x32_w4x2_splitk4"),           # few tiles, long K: it splits K
+    ("float", (256, 8192, 256), False, "mfma_f32_64x64x32_w4x2_splitk8"),
+    ("float", (1536, 1536, 1536), False, "mfma_f32_128x128x32_w4x2_splitk3"),       # 576 tiles of 64 x 64 would be a second round
+    ("float", (1792, 1792, 1792), False, "mfma_f32_128x128x32_w4x2_flush4096"),
+    ("float", (2048, 2048, 2048), False, "mfma_f32_128x128x32_w4x2_flush4096"),     # one workgroup per CU: whole tiles
+    ("float", (2048, 256, 2048), False, "mfma_f32_128x128x32_w4x2_flush4096"),
+    ("float", (2304, 2304, 2304), False, "mfma_f32_128x128x32_w4x2_streamk"),       # between whole rounds: stream-K in teams
+    ("float", (2560, 2560, 2560), False, "mfma_f32_128x128x32_w4x2_streamk"),
+    ("float", (3072, 3072, 3072), False, "mfma_f32_128x128x32_w4x2_streamk"),
+    ("float", (5120, 5120, 5120), False, "mfma_f32_128x128x32_w4x2_streamk"),
+    ("float", (7680, 7680, 7680), False, "mfma_f32_128x128x32_w4x2_streamk"),       # 60 x 60 tiles: 4 x 4 teams divide the grid
+    ("float", (6912, 6912, 6912), False, "mfma_f32_128x256x16_w4x2_flush4096"),     # 54 x 54: only 2 x 2 teams, too big for them
+    ("float", (2816, 2816, 2816), False, "mfma_f32_128x256x16_w4x2_flush4096"),     # whole tiles fit
+    ("float", (4096, 4096, 4096), False, "mfma_f32_128x256x16_w4x2_flush4096"),
+    ("float", (6144, 6144, 6144), False, "mfma_f32_128x128x32_w4x2_flush4096"),
+    ("float", (8192, 8192, 8192), False, "mfma_f32_128x256x16_w4x2_flush4096"),
+    ("float", (16384, 16384, 16384), False, "mfma_f32_128x256x16_w4x2_flush4096"),  # BASELINE configs[1]
+    ("float", (65536, 16384, 16384), False, "mfma_f32_128x256x16_w4x2_flush4096"),  # BASELINE configs[2]
+    ("float", (1024, 1024, 1024), True, "mfma_f32_64x64x32_w4x2_flush4096"),        # K x N A outside whole rounds: transposed first,
+    ("float", (2048, 2048, 2048), True, "mfma_f32_128x128x32_w4x2_flush4096"),      #   then the row-major rules
+    ("float", (6144, 6144, 6144), True, "mfma_f32_128x128x32_w4x2_flush4096"),
+    ("float", (4096, 4096, 4096), True, "mfma_f32_256x256x16_w8_flush4096"),        # whole rounds: the K x N kernel itself
+    ("float", (16384, 16384, 16384), True, "mfma_f32_256x256x16_w8_flush4096"),
+    ("double", (1024, 1024, 1024), False, "mfma_f64_64x64x16_w4x4"),
+    ("double", (3072, 3072, 3072), False, "mfma_f64_64x64x16_w4x4"),
+    ("double", (1792, 1792, 1792), False, "mfma_f64_128x128x16_w4x2"),
+    ("double", (4096, 4096, 4096), False, "mfma_f64_256x128x16_w8"),
+    ("double", (16384, 16384, 16384), False, "mfma_f64_256x128x16_w8"),             # BASELINE configs[3]
+    ("half", (1024, 1024, 1024), False, "mfma_f16_64x256x64_slab64"),
+    ("half", (2560, 2560, 2560), False, "mfma_f16_128x256x64_slab64"),
+    ("half", (4096, 4096, 4096), False, "mfma_f16_256x256_pingpong_16x16x32"),
+    ("half", (32768, 32768, 32768), False, "mfma_f16_256x256_pingpong_16x16x32"),   # BASELINE configs[4]
+    ("uint8_t", (2048, 2048, 2048), False, "mfma_i8_64x256x128_slab128"),
+    ("uint8_t", (2560, 2560, 2560), False, "mfma_i8_256x256_pingpong_16x16x64"),
+    ("uint8_t", (32768, 32768, 32768), False, "mfma_i8_256x256_pingpong_16x16x64"),
+]
+
+
+@pytest.mark.parametrize("dtype,shape,transposed_a,expect", DISPATCH_TABLE,
+                         ids=[f"{d}-{'x'.join(map(str, s))}{'-KxN' if t else ''}" for d, s, t, _ in DISPATCH_TABLE])
+def test_shape_adaptive_dispatch_table(dtype, shape, transposed_a, expect):
+    """mm_kernel_name answers from the resolver the launcher uses (no GPU needed): the measured decisions of the shape-adaptive
+    rules, pinned."""
+    assert g.kernel_name(g.make_config(dtype, transposed_a=transposed_a), *shape) == expect

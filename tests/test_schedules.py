@@ -408,3 +408,60 @@ def test_streamk_ordered_hand_over_random_grids():
     rnd = random.Random(11)
     for _ in range(150):
         _ordered_replay(rnd.randint(1, 45), rnd.randint(1, 45), rnd.randint(1, 160))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The 64 x 64 fp32 geometry (mfma_f32_small_kernel): ring of four stages, four DMA pieces per wavefront per slab.  Prologue:
+# slabs 0..2 whole, wait vmcnt(8), barrier.  During slab t the pieces of slab t+3 are issued one per k-group (the fourth
+# right before the hand-over), then vmcnt(8) + barrier, then slab t+1 is read.  One workgroup, four wavefronts in step.
+@pytest.mark.parametrize("slabs", [1, 2, 3, 4, 5, 9, 32, 129])
+def test_f32_small_geometry_ring_of_four(slabs):
+    waves = []
+    for _ in range(4):
+        w = Wave()
+        for s in range(3):
+            w.issue(s, 4)
+        w.wait_vmcnt(8)
+        w.barrier()
+        w.read(0)                         # first fragments of slab 0 (read_group(0, 0, f0))
+        for t in range(slabs - 1):        # the steady slabs; the last slab is read in the tail loop without refills
+            for g in range(4):            # piece g of slab t+3 after the first MFMA of group g, into the stage slab t-1 left
+                w.read(t)
+                w.issue((t + 3, g), 1)
+            w.wait_vmcnt(8)               # everything but the 8 newest pieces: slab t+1 has landed
+            w.barrier()
+            w.read(t + 1)                 # first fragments of slab t+1
+        w.read(slabs - 1)
+        waves.append(w)
+    for w in waves:                       # fold the four single pieces of a slab into one object
+        for s in range(3, slabs + 2):
+            got = [w.retired.get((s, g)) for g in range(4)]
+            if all(x is not None for x in got):
+                w.retired[s] = max(got)
+        first = {}
+        for e, what in w.issues:
+            if isinstance(what, tuple):
+                first.setdefault(what[0], e)
+        w.issues = [(e, x) for e, x in w.issues if not isinstance(x, tuple)] + [(e, s) for s, e in first.items()]
+    check(waves, lambda slab: slab % 4)
+
+
+def test_f32_small_geometry_a_shorter_ring_would_be_caught():
+    """The same program on a ring of three stages refills the stage that is being read: the checker must object."""
+    waves = []
+    for _ in range(4):
+        w = Wave()
+        for s in range(2):
+            w.issue(s, 4)
+        w.wait_vmcnt(4)
+        w.barrier()
+        w.read(0)
+        for t in range(6):
+            w.read(t)
+            w.issue(t + 2, 4)             # into stage (t + 2) % 3 == (t - 1) % 3 ... but declared as a ring of TWO below
+            w.wait_vmcnt(4)
+            w.barrier()
+            w.read(t + 1)
+        waves.append(w)
+    with pytest.raises(AssertionError):
+        check(waves, lambda slab: slab % 2)
