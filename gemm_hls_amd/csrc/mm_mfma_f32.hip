@@ -116,7 +116,7 @@ struct Geo {
 // One k-range of one output tile: A / B point at the first k of the range (row stride of A: lda), K = its length, the
 // result goes to Cst[row * ldc + col] for rows < Nst, cols < Mst.  For a whole tile of C that is (C, M, N, M); a partial
 // tile of a stream-K launch targets a 128 x 128 scratch slot instead (ldc = 128, no limits).
-template <typename G, bool AT>
+template <typename G, bool AT, bool AGENT_STORES = false>
 __device__ __forceinline__ void tile_body(const float *__restrict__ A, const float *__restrict__ B, float *__restrict__ Cst,
                                           unsigned N, unsigned K, unsigned M, unsigned lda, unsigned ldc, unsigned Nst,
                                           unsigned Mst, unsigned row0, unsigned col0) {
@@ -124,6 +124,16 @@ __device__ __forceinline__ void tile_body(const float *__restrict__ A, const flo
   constexpr bool TWO_LEVEL = G::CHAIN == Chain::TwoLevel, FLUSH = G::CHAIN == Chain::FlushIntoC;
   constexpr bool PIPELINED = G::READS == Reads::Pipelined, SDMA = G::DMA == Dma::ScalarBase;
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  // AGENT_STORES (the scratch slot of a stream-K hand-over, read by a workgroup on another XCD): the predicated stores go out
+  // at agent scope (sc1: written through this XCD's L2 to the agent's coherence point), so that the hand-over needs no
+  // write-back of the whole L2 -- see mfma_f32_streamk_ordered_kernel.  Inline asm, because the language has no 16-byte
+  // scoped store; the compiler's hazard recogniser does not look inside it, so the wait state a store of more than 8 bytes
+  // needs before its data registers are written again (the compiler inserts it for its own stores) is part of the statement.
+  static_assert(!AGENT_STORES || G::TM == 1, "agent-scope stores are wired into the predicated write-back only");
+  auto store_quad = [](f32x4 *dst, f32x4 v) {
+    if constexpr (AGENT_STORES) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
+    else *dst = v;
+  };
 
   const unsigned lane = threadIdx.x & 63u;
   const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -325,7 +335,7 @@ __device__ __forceinline__ void tile_body(const float *__restrict__ A, const flo
 #pragma unroll
           for (int tt = 0; tt < TN; ++tt) v[tt] = acc[mi][tt][r];
           if (accumulate) v += *dst;
-          *dst = v;
+          store_quad(dst, v);
         }
       }
 #pragma unroll
@@ -524,7 +534,7 @@ __device__ __forceinline__ void tile_body(const float *__restrict__ A, const flo
               v[tt] = x;
             }
             if (accumulate) v += *dst;
-            *dst = v;
+            store_quad(dst, v);
           }
         }
       }
@@ -859,13 +869,10 @@ __global__ __launch_bounds__(G::THREADS, G::MIN_WAVES) void mfma_f32_streamk_ord
     } else if (s0 > 0) {   // not the lowest-k segment: this workgroup's first segment -> its slot, then the flag
       float *slot = slots + (size_t)w * (G::BM * G::BN);
       float *base = (float *)((unsigned long long)slot - ((unsigned long long)row0 * G::BN + col0) * sizeof(float));
-      tile_body<G, false>(a, b, base, N, klen, M, K, G::BN, ~0u, ~0u, row0, col0);
+      tile_body<G, false, true>(a, b, base, N, klen, M, K, G::BN, ~0u, ~0u, row0, col0);   // slot stores at agent scope
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every wavefront: its slot stores have reached the agent's coherence point
       __syncthreads();
-      if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_store(flags + w, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // raised = holds this launch's epoch
-      }
+      if (threadIdx.x == 0) __hip_atomic_store(flags + w, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // raised = holds this launch's epoch
     } else {               // the lowest-k segment of a split tile: this one into C, then the others on top in ascending k
       tile_body<G, false>(a, b, C, N, klen, M, K, M, N, M, row0, col0);
       const unsigned u_hi = st * spt + spt;

@@ -212,7 +212,8 @@ def test_f32_split_k_for_small_problems_is_deterministic_and_accurate(shape, spl
 
 @pytest.mark.parametrize("shape,forced", [((2304, 2304, 2304), False), ((3072, 1056, 520), True), ((1000, 96, 3000), True),
                                           ((2560, 512, 2560), False), ((129, 4096, 132), True), ((3584, 256, 3584), False), ((100, 96, 120), True), ((300, 64, 272), True),
-                                          ((5120, 256, 5120), False), ((2341, 2304, 2304), True), ((128, 32768, 128), True), ((2432, 288, 3712), False)],
+                                          ((5120, 256, 5120), False), ((2341, 2304, 2304), True), ((128, 32768, 128), True), ((2432, 288, 3712), False),
+                                          ((2304, 8448, 2304), False)],   # a workgroup's part of a tile > 4128 k: the chain is flushed INTO the scratch slot
                          ids=lambda v: "x".join(map(str, v)) if isinstance(v, tuple) else ("forced" if v else "auto"))
 def test_f32_stream_k_for_partial_rounds_is_deterministic_and_accurate(shape, forced):
     """Round 3: problems of a few partial rounds of 128 x 128 tiles are dealt out to 512 persistent workgroups in equal
