@@ -11,7 +11,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
-#include <unordered_set>
+#include <random>
+#include <unordered_map>
 #include <string>
 #include <vector>
 
@@ -44,6 +45,7 @@ int hip_fail(hipError_t e, const char *what) {
 // calls from any number of host threads; g_error above is per thread) -------------------------
 std::once_flag g_init_once;
 int g_device_count = 0;
+int g_device_cus[64] = {};   // compute units each device reports (MI355X in SPX mode: 256; a CPX partition: 32)
 int g_init_status = MM_ERR_NO_DEVICE;
 char g_init_error[512] = "";
 
@@ -67,6 +69,7 @@ void init_once() {
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
       return init_fail("device %d is %s; the kernels in this library are built for gfx950 only "
                        "(hide other devices with HIP_VISIBLE_DEVICES)", d, prop.gcnArchName);
+    if (d < 64) g_device_cus[d] = prop.multiProcessorCount;
   }
   g_device_count = n;
   g_init_status = MM_OK;
@@ -88,9 +91,9 @@ mm_config_t default_cfg() {
 std::once_flag g_tuning_once;
 std::atomic<int> g_tuning[mm::TUNE_COUNT];
 const char *const kTuneName[mm::TUNE_COUNT] = {"f32_variant", "f64_variant", "f16_variant", "i8_variant", "band_rows",
-                                               "valu_variant", "split_variant", "f32_splitk", "ablations"};
+                                               "valu_variant", "split_variant", "f32_splitk", "ablations", "debug_poison"};
 const char *const kTuneEnv[mm::TUNE_COUNT] = {"MM_F32_VARIANT", "MM_F64_VARIANT", "MM_F16_VARIANT", "MM_I8_VARIANT",
-                                              "MM_BAND_ROWS", "MM_VALU_VARIANT", "MM_SPLIT_VARIANT", "MM_F32_SPLITK", "MM_ABLATIONS"};
+                                              "MM_BAND_ROWS", "MM_VALU_VARIANT", "MM_SPLIT_VARIANT", "MM_F32_SPLITK", "MM_ABLATIONS", "MM_DEBUG_POISON"};
 void tuning_init() {
   for (int i = 0; i < mm::TUNE_COUNT; ++i) {
     const char *e = getenv(kTuneEnv[i]);
@@ -227,8 +230,15 @@ int mm::workspace_pool(int dev, hipMemPool_t *out) {
 // the fill kernel and its dependency gap in front of every launch (~10 us: 4 % of a 2560^3 product).  While the stream is
 // being captured into a graph the block is cleared every time: a replay repeats the epoch it was captured with.
 static hipMemPool_t g_flags_pool[64] = {};
-static std::unordered_set<unsigned long long> g_flags_seen[64];
-static std::atomic<unsigned long long> g_flags_epoch{1};
+static std::unordered_map<unsigned long long, size_t> g_flags_seen[64];   // address -> bytes cleared there
+static unsigned long long g_flags_reserved[64] = {};                    // the pool's reserved bytes when last looked at
+// Epochs start from a random 64-bit base per process: what is left in recycled memory -- a small integer,
+// an index buffer, an epoch of another process -- cannot plausibly equal a live epoch even if a block were ever missed.
+static unsigned long long flags_epoch_base() {
+  std::random_device rd;
+  return (((unsigned long long)rd() << 32) ^ (unsigned long long)rd() ^ (unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count()) | (1ull << 62);
+}
+static std::atomic<unsigned long long> g_flags_epoch{flags_epoch_base()};
 int mm::flags_alloc(int dev, hipStream_t s, size_t bytes, void **out, unsigned long long *epoch) {
   std::lock_guard<std::mutex> lock(g_workspace_mu);
   hipMemPool_t &pool = g_flags_pool[dev & 63];
@@ -238,14 +248,77 @@ int mm::flags_alloc(int dev, hipStream_t s, size_t bytes, void **out, unsigned l
   hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
   if ((e = hipStreamIsCapturing(s, &capture)) != hipSuccess) { (void)hipFreeAsync(*out, s); return (int)e; }
   *epoch = g_flags_epoch.fetch_add(1, std::memory_order_relaxed);
+  // The pool mapped or unmapped memory since the last look (the runtime may trim a pool by itself when the device runs
+  // out of memory): an address seen before may be backed by fresh physical memory now -- forget what was cleared.
+  unsigned long long reserved = 0;
+  if (hipMemPoolGetAttribute(pool, hipMemPoolAttrReservedMemCurrent, &reserved) == hipSuccess && reserved != g_flags_reserved[dev & 63]) {
+    g_flags_reserved[dev & 63] = reserved;
+    g_flags_seen[dev & 63].clear();
+  }
   // (a block handed out during capture is not recorded: whether the graph ever runs and clears it is not known here)
   const bool capturing = capture != hipStreamCaptureStatusNone;
-  const bool first_time = !capturing && g_flags_seen[dev & 63].insert((unsigned long long)(size_t)*out).second;
-  if (first_time || capturing) {
+  bool clear = capturing;
+  if (!capturing) {
+    size_t &cleared = g_flags_seen[dev & 63][(unsigned long long)(size_t)*out];   // 0 when the address is new
+    if (cleared < bytes) { cleared = bytes; clear = true; }                        // new, or seen with fewer bytes
+  }
+  if (clear) {
     if ((e = hipMemsetAsync(*out, 0, bytes, s)) != hipSuccess) { (void)hipFreeAsync(*out, s); return (int)e; }
   }
   return 0;
 }
+
+// Stream-K with the hand-over inside the launch (mm_mfma_f32.hip: mfma_f32_streamk_ordered_kernel) has workgroups wait
+// on flags that other workgroups of the SAME launch raise.  That is only sound when every workgroup of the launch gets a
+// place on the chip without one of the waiting ones having to leave first:
+//   * the device has the 256 CUs (8 XCDs x 32) the launch's 512 places are counted on, and the stream is not CU-masked;
+//   * no second launch of that kind competes for the places: two of them, each holding part of the chip with workgroups
+//     that wait for workgroups the other one keeps from being dispatched, would wait for ever.  So such
+//     launches are serialised per device: each one's stream first waits for the event recorded behind the previous one
+//     (ordinary kernels next to it are fine -- they finish and hand their places over);
+//   * the stream is not being captured: replays of a graph are launched by the application, outside this ordering.
+// Where any of this does not hold, the launcher runs the two-kernel form (slots for every part, a fix-up kernel adds
+// them in ascending k: no waiting inside a kernel), equally deterministic.
+static hipEvent_t g_streamk_event[64] = {};
+static hipStream_t g_streamk_stream[64] = {};
+static bool g_streamk_any[64] = {};
+static std::mutex g_streamk_mu;
+int mm::streamk_ordered_admit(int dev, hipStream_t s, bool *admitted) {
+  *admitted = false;
+  if (dev < 0 || dev >= 64 || g_device_cus[dev] != 256) return 0;
+  hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+  hipError_t e = hipStreamIsCapturing(s, &capture);
+  if (e != hipSuccess) return (int)e;
+  if (capture != hipStreamCaptureStatusNone) return 0;
+  uint32_t mask[8] = {};
+  e = hipExtStreamGetCUMask(s, 8, mask);
+  if (e == hipSuccess) {
+    int cus = 0;
+    for (uint32_t w : mask) cus += __builtin_popcount(w);
+    if (cus != 256) return 0;
+  } else {
+    (void)hipGetLastError();
+    if (s != nullptr) return 0;        // a stream whose mask cannot be read is treated as masked; the null stream has none of its own
+  }
+  std::lock_guard<std::mutex> lock(g_streamk_mu);
+  if (!g_streamk_event[dev]) {
+    if ((e = hipEventCreateWithFlags(&g_streamk_event[dev], hipEventDisableTiming)) != hipSuccess) { g_streamk_event[dev] = nullptr; return (int)e; }
+  }
+  if (g_streamk_any[dev] && g_streamk_stream[dev] != s) {
+    if ((e = hipStreamWaitEvent(s, g_streamk_event[dev], 0)) != hipSuccess) return (int)e;
+  }
+  *admitted = true;
+  return 0;
+}
+int mm::streamk_ordered_launched(int dev, hipStream_t s) {
+  std::lock_guard<std::mutex> lock(g_streamk_mu);
+  const hipError_t e = hipEventRecord(g_streamk_event[dev], s);
+  g_streamk_stream[dev] = s;
+  g_streamk_any[dev] = true;
+  return (int)e;
+}
+int mm::device_compute_units(int dev) { return dev >= 0 && dev < 64 && g_device_cus[dev] > 0 ? g_device_cus[dev] : 256; }
+
 int mm::workspace_release(int dev) {
   std::lock_guard<std::mutex> lock(g_workspace_mu);
   int rc = 0;
@@ -470,7 +543,7 @@ int mm_gemm_multi_device(int device_count, const mm_config_t *cfg, const void *a
     Dev &d = devs[g];
     if (!d.rows) continue;
     MM_HIP_MD(hipSetDevice(g));
-    mm::Problem warm{d.a, d.b, d.c, d.rows, k, m, false, n};
+    mm::Problem warm{d.a, d.b, d.c, d.rows, k, m, false, d.rows == n ? 0u : n};
     rc = dispatch(d.s, *cfg, warm);
     if (rc) { cleanup(); return rc; }
   }
@@ -481,7 +554,7 @@ int mm_gemm_multi_device(int device_count, const mm_config_t *cfg, const void *a
     Dev &d = devs[g];
     if (!d.rows) continue;
     MM_HIP_MD(hipSetDevice(g));
-    mm::Problem p{d.a, d.b, d.c, d.rows, k, m, false, n};   // a row slab of the n-row job
+    mm::Problem p{d.a, d.b, d.c, d.rows, k, m, false, d.rows == n ? 0u : n};   // a row slab of the n-row job (0: the slab IS the job -- the same launch as mm_gemm_launch's)
     rc = dispatch(d.s, *cfg, p);
     if (rc) { cleanup(); return rc; }
   }
@@ -638,7 +711,7 @@ int mm_kernel_info(const mm_config_t *cfg, unsigned n, unsigned k, unsigned m, m
   if (!valid_cfg(cfg) || !info) return fail(MM_ERR_BAD_ARGUMENT, "invalid arguments to mm_kernel_info");
   mm::Problem p{nullptr, nullptr, nullptr, n, k, m, cfg->layout_a == MM_A_TRANSPOSED};
   mm_kernel_info_t r = {};
-  r.compute_units = 256;
+  r.compute_units = (unsigned)mm::device_compute_units(0);   // what device 0 reports once the library is initialised; the MI355X's 256 before
   r.max_clock_mhz = 2400.0;
   switch (choose(*cfg, p)) {
     case FAM_MFMA_F32:

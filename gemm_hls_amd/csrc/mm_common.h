@@ -97,6 +97,12 @@ int workspace_pool(int device, hipMemPool_t *pool);      // the library-owned, s
 int workspace_release(int device);                       // hands its cached memory back to the driver
 // `bytes` of hand-over flags for one launch on `stream` (free with hipFreeAsync), and the launch's epoch: mm_capi.hip
 int flags_alloc(int device, hipStream_t stream, size_t bytes, void **flags, unsigned long long *epoch);
+// Stream-K's in-launch hand-over needs the whole chip and no second launch of its kind next to it (mm_capi.hip):
+// `admitted` = this launch may take that form on (device, stream) -- the stream has then been ordered behind the previous
+// such launch; otherwise the caller runs the two-kernel form.  _launched records the event the next one waits on.
+int streamk_ordered_admit(int device, hipStream_t stream, bool *admitted);
+int streamk_ordered_launched(int device, hipStream_t stream);
+int device_compute_units(int device);                    // as reported by the device when the library initialised
 int mfma_f32_splitk(const Problem &p, int variant);      // K chunks the fp32 MFMA launcher uses for (problem, resolved variant)
 bool mfma_f32_serves(const Problem &p);
 bool mfma_f64_serves(const Problem &p);
@@ -145,6 +151,8 @@ enum Tunable {
   TUNE_F32_SPLITK,       // MM_F32_SPLITK   fp32 MFMA path: -1 by shape (small problems only), 1 never, 2..8 that many K chunks
   TUNE_ABLATIONS,        // MM_ABLATIONS    1 = allow the variants that skip work on purpose (power breakdown
                          //                 measurements; they produce WRONG results and are refused otherwise)
+  TUNE_DEBUG_POISON,     // MM_DEBUG_POISON 1 = fill scratch the kernels hand data through (stream-K slots) with NaN before
+                         //                 every launch: a read of anything this launch did not write shows up in C
   TUNE_COUNT
 };
 int tuning(Tunable t);  // mm_capi.hip

@@ -831,8 +831,13 @@ __global__ __launch_bounds__(G::THREADS, G::MIN_WAVES) void mfma_f32_streamk_ker
 // their scratch slot and raise a flag right away; the owner of the lowest-k segment writes its sum to C, waits for those
 // flags (raised by first segments, normally long ago) and adds the slots on top in ascending k -- C = own + slot + slot ...
 // A fixed order, no atomics on data, no second kernel and half the scratch.  Waits point at higher workgroup ids only,
-// are the last thing a workgroup does and never aim at a segment that itself waits, so the launch makes progress
-// whatever the residency (workgroups are dispatched in id order within an XCD; w + 1 is blockIdx + 8 or XCD x+1's first).  Visibility: the producer's stores, __syncthreads, one lane's agent-scope
+// are the last thing a workgroup does and never aim at a segment that itself waits.  FORWARD PROGRESS is nevertheless a
+// property of the launch, not of the kernel: a waiting workgroup keeps its place on its CU, so every workgroup it waits
+// for must find a place without it leaving -- true when all 512 workgroups fit the chip at once (256 CUs x 2) next to
+// kernels that finish on their own, false on a CU-masked stream, on a partitioned device, or next to a second launch of
+// this kind (each holding places the other's producers need).  launch_streamk_ordered therefore only runs this kernel
+// after streamk_ordered_admit() (mm_capi.hip) has checked the device and the stream and ordered the launch behind the
+// previous one of its kind; everything else takes the two-kernel form above.  Visibility: the producer's stores, __syncthreads, one lane's agent-scope
 // release + s_waitcnt vmcnt(0) + relaxed agent store of the flag; the consumer's relaxed poll by one lane, agent-scope
 // acquire, __syncthreads, plain loads (MI355X_MICROARCH.md, inter-workgroup visibility: the valid forms).
 //
@@ -918,6 +923,9 @@ static TeamShape streamk_team_shape(unsigned tiles_n, unsigned tiles_m) {
 }
 
 template <typename G>
+int launch_streamk(hipStream_t s, const Problem &p);   // the two-kernel form, below
+
+template <typename G>
 int launch_streamk_ordered(hipStream_t s, const Problem &p) {
   const unsigned tiles_n = (p.n + G::BM - 1) / G::BM, tiles_m = (p.m + G::BN - 1) / G::BN, spt = p.k / G::BK;
   const TeamShape ts = streamk_team_shape(tiles_n, tiles_m);
@@ -925,8 +933,7 @@ int launch_streamk_ordered(hipStream_t s, const Problem &p) {
   const unsigned long long super_tiles = (unsigned long long)(tiles_n / ts.sr) * (tiles_m / ts.sc), units = super_tiles * spt;
   // every place gets a team when there is work for it: a team's range is at least 8 slabs (below that the fill and drain
   // of the rings outweigh the slabs -- the chunk floor of split-K) and a tile is cut at most 8 ways (the gather is serial
-  // in the owner of the lowest part, and a wait never aims further than 8 teams ahead -- with workgroups dispatched in id
-  // order a launch therefore keeps moving on whatever share of the chip it gets next to other kernels)
+  // in the owner of the lowest part, and a wait never aims further than 8 teams ahead)
   const unsigned teams = (unsigned)std::max<unsigned long long>(1, std::min<unsigned long long>({8ull * teams_per_xcd, units / 8, 8 * super_tiles}));
   static_assert(G::MIN_WAVES == 2, "two workgroups per CU: 64 places per XCD");
   static unsigned long long configured = 0;
@@ -936,8 +943,14 @@ int launch_streamk_ordered(hipStream_t s, const Problem &p) {
   if (e != hipSuccess) return (int)e;
   hipMemPool_t pool = nullptr;
   if (int rc = workspace_pool(dev, &pool)) return rc;
+  // the whole chip, an unmasked stream, no capture, and ordered behind the previous launch of this kind: else the two-kernel form
+  bool admitted = false;
+  if (int rc = streamk_ordered_admit(dev, s, &admitted)) return rc;
+  if (!admitted) return launch_streamk<G>(s, p);
   float *slots = nullptr;
-  if ((e = hipMallocFromPoolAsync((void **)&slots, (size_t)nwg * G::BM * G::BN * sizeof(float), pool, s)) != hipSuccess) return (int)e;
+  const size_t slot_bytes = (size_t)nwg * G::BM * G::BN * sizeof(float);
+  if ((e = hipMallocFromPoolAsync((void **)&slots, slot_bytes, pool, s)) != hipSuccess) return (int)e;
+  if (tuning(TUNE_DEBUG_POISON) == 1 && (e = hipMemsetAsync(slots, 0xFF, slot_bytes, s)) != hipSuccess) { (void)hipFreeAsync(slots, s); return (int)e; }   // NaN everywhere
   void *flags = nullptr;
   unsigned long long epoch = 0;
   if (int rc = flags_alloc(dev, s, nwg * sizeof(unsigned long long), &flags, &epoch)) { (void)hipFreeAsync(slots, s); return rc; }
@@ -945,7 +958,8 @@ int launch_streamk_ordered(hipStream_t s, const Problem &p) {
   hipLaunchKernelGGL((mfma_f32_streamk_ordered_kernel<G>), dim3(nwg), dim3(G::THREADS), G::LDS_BYTES, s, (const float *)p.a,
                      (const float *)p.b, (float *)p.c, p.n, p.k, p.m, tiles_n, tiles_m, spt, ts.sr, ts.sc, teams_per_xcd, teams,
                      slots, (unsigned long long *)flags, epoch);
-  const int rc = (int)hipGetLastError();
+  int rc = (int)hipGetLastError();
+  if (rc == 0) rc = streamk_ordered_launched(dev, s);
   const hipError_t f1 = hipFreeAsync(flags, s), f2 = hipFreeAsync(slots, s);
   return rc ? rc : f1 != hipSuccess ? (int)f1 : (int)f2;
 }
@@ -996,7 +1010,9 @@ int launch_streamk(hipStream_t s, const Problem &p) {
   hipMemPool_t pool = nullptr;
   if (int rc = workspace_pool(dev, &pool)) return rc;
   float *slots = nullptr;
-  if ((e = hipMallocFromPoolAsync((void **)&slots, (size_t)nwg * 2 * G::BM * G::BN * sizeof(float), pool, s)) != hipSuccess) return (int)e;
+  const size_t slot_bytes = (size_t)nwg * 2 * G::BM * G::BN * sizeof(float);
+  if ((e = hipMallocFromPoolAsync((void **)&slots, slot_bytes, pool, s)) != hipSuccess) return (int)e;
+  if (tuning(TUNE_DEBUG_POISON) == 1 && (e = hipMemsetAsync(slots, 0xFF, slot_bytes, s)) != hipSuccess) { (void)hipFreeAsync(slots, s); return (int)e; }   // NaN everywhere
   (void)hipGetLastError();
   const unsigned kband = band_rows(G::BM, G::BN, G::MIN_WAVES);
   hipLaunchKernelGGL((mfma_f32_streamk_kernel<G>), dim3(nwg), dim3(G::THREADS), G::LDS_BYTES, s, (const float *)p.a, (const float *)p.b,

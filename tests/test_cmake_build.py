@@ -40,6 +40,36 @@ def test_default_configuration_builds_the_reference_targets(tmp_path):
     assert "TestSimulation" in t.stdout and "513" in t.stdout and "528" in t.stdout
 
 
+def _compile_flags(build):
+    out = ""
+    for root, _, files in os.walk(build / "CMakeFiles"):
+        for f in files:
+            if f == "flags.make":
+                out += open(os.path.join(root, f)).read()
+    return out
+
+
+def test_reconfiguring_does_not_pin_the_tile(tmp_path):
+    """the tile knob's intent must not depend on how many times cmake ran.  Not given: never pinned, however
+    often the tree is re-configured; given once: pinned on every later configure (the cache keeps the user's value)."""
+    build, r = _configure(tmp_path)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "MM_MEMORY_TILE_SIZE_N" not in _compile_flags(build)
+    for _ in range(2):
+        r = subprocess.run(["cmake", str(build)], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "MM_MEMORY_TILE_SIZE_N" not in _compile_flags(build)
+    r = subprocess.run(["cmake", str(build), "-DMM_MEMORY_TILE_SIZE_N=128", "-DMM_MEMORY_TILE_SIZE_M=256"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    for _ in range(2):
+        flags = _compile_flags(build)
+        assert "MM_MEMORY_TILE_SIZE_N=128" in flags and "MM_MEMORY_TILE_SIZE_M=256" in flags
+        r = subprocess.run(["cmake", str(build)], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0
+    t = subprocess.run(["ctest", "-N", "-V"], cwd=build, capture_output=True, text=True)
+    assert "257" in t.stdout and "528" in t.stdout       # CTest sizes follow the given tile: 2*128+1, 2*256+16
+
+
 def test_static_half_transposed_power_configuration(tmp_path):
     build, r = _configure(tmp_path, "-DMM_DATA_TYPE=half", "-DMM_DYNAMIC_SIZES=OFF", "-DMM_SIZE_N=528", "-DMM_SIZE_K=512",
                           "-DMM_SIZE_M=576", "-DMM_TRANSPOSED_A=ON", "-DMM_POWER_METER=ON", "-DMM_MAP_OP=Multiply",

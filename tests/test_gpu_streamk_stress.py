@@ -1,0 +1,153 @@
+"""Stress of the stream-K hand-over (gemm_hls_amd/csrc/mm_mfma_f32.hip: mfma_f32_streamk_ordered_kernel) -- partial tiles
+pass from workgroup to workgroup INSIDE a launch through scratch slots and epoch flags.  What a clean run cannot see:
+
+  * a stale read of a slot that an EARLIER launch of the same operands wrote is bit-identical to the right answer.  So
+    every launch here runs with the library's `debug_poison` knob: the slot pool is filled with NaN first, and a read of
+    anything this launch did not write (or wrote too late) puts NaN into C; shapes alternate so that a slot's previous
+    contents never belong to the same tile; the whole matrix is compared, bit for bit, with the result of an unloaded run,
+    which is itself checked against fp64;
+  * forward progress: a workgroup waiting inside the launch holds its CU.  The library admits the hand-over form only on
+    the whole chip, unmasked, outside capture and one such launch at a time (mm_capi.hip: streamk_ordered_admit); a
+    CU-masked stream must get the two-kernel form -- run in a child process under a watchdog, because the failure mode
+    of getting it wrong is a GPU that never comes back.
+
+Reference semantics kept: one deterministic k-ordered result per element (kernel/Compute.cpp:108-142)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import _bounds
+import gemm_hls_amd as g
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+# (shape, forced): auto = the shape-adaptive rule takes stream-K by itself; forced = f32_splitk 0 on the 128 x 128 geometry
+CASES = [((2304, 256, 2304), False), ((2560, 512, 2560), False), ((3584, 256, 3584), False), ((2432, 288, 3712), False),
+         ((2341, 2304, 2304), True),      # ragged N, a tile cut several ways
+         ((640, 12352, 384), True),       # 15 tiles x 386 slabs: a part of a tile longer than 2 x 4096 k -> three flushes INTO its slot
+         ((129, 4096, 132), True)]        # 4 tiles over 512 workgroups: every tile cut the maximum number of ways
+
+
+@pytest.fixture(autouse=True)
+def _knobs():
+    yield
+    for knob in ("f32_variant", "f32_splitk", "debug_poison"):
+        g.set_tuning(knob, -1)
+
+
+def _run(a, b, forced):
+    g.set_tuning("f32_variant", 35 if forced else -1)
+    g.set_tuning("f32_splitk", 0 if forced else -1)
+    return g.matmul(a, b)
+
+
+def test_poisoned_slots_alternating_shapes_under_background_load():
+    import torch
+    dev = torch.device("cuda:0")
+    ops, clean = [], []
+    for i, ((n, k, m), forced) in enumerate(CASES):
+        a = torch.empty((n, k), device=dev).uniform_(-3, 10, generator=torch.Generator(device=dev).manual_seed(100 + i))
+        b = torch.empty((k, m), device=dev).uniform_(-3, 10, generator=torch.Generator(device=dev).manual_seed(200 + i))
+        g.set_tuning("f32_variant", 35 if forced else -1)
+        g.set_tuning("f32_splitk", 0 if forced else -1)
+        assert g.kernel_name(g.make_config("float"), n, k, m) == "mfma_f32_128x128x32_w4x2_streamk", (n, k, m)
+        c = _run(a, b, forced).clone()
+        exact = a.double() @ b.double()
+        scale = a.double().abs() @ b.double().abs()
+        err = float(((c.double() - exact).abs() / scale).max())
+        _bounds.north_star(err, f"stream-K {n}x{k}x{m}")
+        _bounds.guard(err, _bounds.f32_chain_guard(k), f"stream-K {n}x{k}x{m}")
+        ops.append((a, b, forced))
+        clean.append(c)
+        del exact, scale
+    # background load on a second stream: memory traffic and a whole-tile GEMM, uneven in length
+    side = torch.cuda.Stream()
+    noise = torch.empty(32 << 20, dtype=torch.float32, device=dev)
+    na, nb = torch.rand((2048, 2048), device=dev), torch.rand((2048, 2048), device=dev)
+    g.set_tuning("debug_poison", 1)
+    launches, bad = 0, []
+    order = np.random.default_rng(7)
+    for rep in range(300):
+        with torch.cuda.stream(side):
+            if rep % 3 == 0:
+                noise.add_(1.0)
+            if rep % 5 == 0:
+                torch.mm(na, nb)
+        for i in order.permutation(len(ops)):        # a slot's previous contents come from another shape's tiles
+            a, b, forced = ops[i]
+            c = _run(a, b, forced)
+            launches += 1
+            if not torch.equal(c, clean[i]):
+                nan = int(torch.isnan(c).sum())
+                bad.append((rep, CASES[i][0], nan, int((c != clean[i]).sum())))
+        if bad:
+            break
+    torch.cuda.synchronize()
+    assert not bad, f"hand-over read what this launch had not written (rep, shape, NaNs, differing elements): {bad[:4]}"
+    assert launches >= 2000, launches
+
+
+def test_poison_knob_really_poisons_and_the_fixup_form_passes_it_too():
+    """The knob is only worth something if a missed write WOULD show: the two-kernel form (f32_splitk 9) reads slots of
+    every part of a cut tile, so with poison on it must still be exact -- and the pool it draws from must hold NaN when
+    handed out (checked through a fresh allocation from the same torch-invisible pool indirectly: a launch whose slots
+    were NOT all written, i.e. a tile cut fewer ways than slots exist, leaves NaN only outside C)."""
+    import torch
+    dev = torch.device("cuda:0")
+    n, k, m = 2341, 2304, 2304
+    a = torch.empty((n, k), device=dev).uniform_(-3, 10)
+    b = torch.empty((k, m), device=dev).uniform_(-3, 10)
+    g.set_tuning("f32_variant", 35)
+    g.set_tuning("f32_splitk", 9)
+    plain = g.matmul(a, b).clone()
+    g.set_tuning("debug_poison", 1)
+    for _ in range(20):
+        assert torch.equal(g.matmul(a, b), plain)
+    assert not bool(torch.isnan(plain).any())
+
+
+_MASKED_CHILD = r"""
+import ctypes, os, sys
+import torch
+sys.path.insert(0, {root!r})
+import gemm_hls_amd as g
+hip = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+hip.hipExtStreamCreateWithCUMask.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32)]
+dev = torch.device("cuda:0")
+n, k, m = 2341, 2304, 2304
+a = torch.empty((n, k), device=dev).uniform_(-3, 10)
+b = torch.empty((k, m), device=dev).uniform_(-3, 10)
+assert g.kernel_name(g.make_config("float"), n, k, m).endswith("streamk")
+ordered = g.matmul(a, b).clone()
+g.set_tuning("f32_variant", 35); g.set_tuning("f32_splitk", 9)
+fixup = g.matmul(a, b).clone()
+g.set_tuning("f32_variant", -1); g.set_tuning("f32_splitk", -1)
+torch.cuda.synchronize()
+mask = (ctypes.c_uint32 * 8)(*([0x0000FFFF] * 8))          # half of every XCD's CUs: 128 places for 512 workgroups
+stream = ctypes.c_void_p()
+rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(stream), 8, mask)
+if rc != 0:
+    print("SKIP hipExtStreamCreateWithCUMask rc", rc); sys.exit(0)
+out = torch.empty((n, m), device=dev)
+cfg = g.make_config("float")
+for _ in range(5):
+    g._check(g.lib().mm_gemm_enqueue(stream, ctypes.byref(cfg), a.data_ptr(), b.data_ptr(), out.data_ptr(), n, k, m))
+torch.cuda.synchronize()
+print("masked==fixup", bool(torch.equal(out, fixup)), "masked==ordered", bool(torch.equal(out, ordered)),
+      "ordered==fixup", bool(torch.equal(ordered, fixup)))
+"""
+
+
+def test_cu_masked_stream_gets_the_two_kernel_form_and_finishes():
+    code = _MASKED_CHILD.format(root=ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=180, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    if "SKIP" in r.stdout:
+        pytest.skip(r.stdout.strip())
+    assert "masked==fixup True" in r.stdout, r.stdout
+    if "ordered==fixup False" in r.stdout:
+        assert "masked==ordered False" in r.stdout, r.stdout

@@ -1,0 +1,105 @@
+"""The machine code of the hand-synchronised stream-K kernel (gemm_hls_amd/csrc/mm_mfma_f32.hip:
+mfma_f32_streamk_ordered_kernel), checked on the gfx950 ISA hipcc emits for the shipped source with the build's flags.
+
+The kernel hands partial tiles from one workgroup to another INSIDE a launch through scratch slots and epoch flags, with
+hand-written agent-scope (sc1) stores.  Its memory ordering is a contract between the source (inline asm included) and
+the compiler; a compiler bump or an innocent-looking edit can break it silently -- results would still be right most
+of the time.  This test pins what a reviewer checks by hand:
+
+  producer  every slot store is `global_store_dwordx4 ... sc1` and is followed by a wait state (`s_nop`): a store of more
+            than 8 bytes reads its data registers late, the next VALU write to them would otherwise be stored instead;
+            then `s_waitcnt vmcnt(0)` (each wavefront: its slot stores have reached the coherence point), `s_barrier`
+            (all wavefronts have), and only then ONE lane's `global_store_dwordx2 ... sc1` of the flag -- no other store
+            in between;
+  consumer  the poll is an sc1 load (never served from this CU's non-coherent lines) in a loop with `s_sleep`; after it
+            `s_waitcnt vmcnt(0)`, `buffer_inv sc1` (drop stale lines before the slots are read), `s_barrier` (the other
+            wavefronts do not start early), and only then the gather's `global_load_dwordx4`;
+  data      no atomics on data anywhere: the order of additions is fixed (kernel/Compute.cpp:108-142: one deterministic
+            k-ordered result per element).
+
+CPU test: hipcc cross-compiles the translation unit to assembly here (about 15 s)."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "gemm_hls_amd", "csrc", "mm_mfma_f32.hip")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+@pytest.fixture(scope="module")
+def ordered_kernels():
+    from gemm_hls_amd import build
+    flags = [f for f in build.COMMON if f != "--offload-compress"]          # the flags the shipped object is built with
+    r = subprocess.run([HIPCC, *flags, "-S", "--cuda-device-only", SRC, "-o", "-"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = r.stdout.split("\n")
+    kernels, name, body = {}, None, []
+    for ln in lines:
+        m = re.match(r"^(_Z\w+):\s*; @", ln)
+        if m:
+            name, body = m.group(1), []
+            continue
+        if name is None:
+            continue
+        t = ln.split(";")[0].strip()
+        if ln.lstrip().startswith(";;#ASM"):        # keep inline-asm brackets out, their contents in
+            continue
+        if t and not t.startswith("."):
+            body.append(t)
+        if "s_endpgm" in t:
+            kernels[name] = body
+            name = None
+    picked = {k: v for k, v in kernels.items() if "mfma_f32_streamk_ordered_kernel" in k}
+    assert len(picked) == 2, list(kernels)           # scalar-base DMA and vector-address twins
+    return picked
+
+
+def _is(op, ins):
+    return ins.split()[0] == op
+
+
+def test_slot_stores_are_agent_scope_and_followed_by_a_wait_state(ordered_kernels):
+    for name, body in ordered_kernels.items():
+        idx = [i for i, t in enumerate(body) if _is("global_store_dwordx4", t) and t.endswith("sc1")]
+        assert len(idx) >= 16, (name, len(idx))      # a 128 x 128 tile of a 256-thread workgroup: 16 quads per thread, per write-back form
+        for i in idx:
+            assert _is("s_nop", body[i + 1]), (name, body[i], body[i + 1])
+
+
+def test_flag_is_raised_by_one_sc1_store_after_waitcnt_and_barrier(ordered_kernels):
+    for name, body in ordered_kernels.items():
+        flag = [i for i, t in enumerate(body) if _is("global_store_dwordx2", t)]
+        assert len(flag) == 1 and body[flag[0]].endswith("sc1"), (name, [body[i] for i in flag])
+        i = flag[0]
+        back = body[max(0, i - 40):i]
+        bar = max(j for j, t in enumerate(back) if _is("s_barrier", t))          # the barrier in front of the flag store
+        assert not any(t.startswith("global_store") or t.startswith("buffer_store") for t in back[bar:]), (name, back[bar:])
+        waits = [j for j, t in enumerate(back[:bar]) if _is("s_waitcnt", t) and "vmcnt(0)" in t]
+        assert waits, (name, back)
+        # nothing that stores between that waitcnt and the barrier either
+        assert not any(t.startswith("global_store") for t in back[waits[-1]:bar]), (name, back[waits[-1]:bar])
+
+
+def test_poll_is_an_sc1_load_and_the_gather_waits_for_invalidate_and_barrier(ordered_kernels):
+    for name, body in ordered_kernels.items():
+        polls = [i for i, t in enumerate(body) if _is("global_load_dwordx2", t) and t.endswith("sc1")]
+        assert len(polls) >= 1, name
+        assert all(t.endswith("sc1") for t in body if _is("global_load_dwordx2", t)), name     # no plain 8-byte load could be the poll
+        assert any(_is("s_sleep", t) for t in body), name
+        inv = [i for i, t in enumerate(body) if t == "buffer_inv sc1"]
+        assert len(inv) == 1, (name, inv)
+        i = inv[0]
+        assert _is("s_waitcnt", body[i - 1]) and "vmcnt(0)" in body[i - 1], (name, body[i - 1])
+        after = body[i + 1:]
+        first_barrier = next(j for j, t in enumerate(after) if _is("s_barrier", t))
+        first_gather = next(j for j, t in enumerate(after) if _is("global_load_dwordx4", t))
+        assert first_barrier < first_gather, (name, first_barrier, first_gather)
+
+
+def test_no_atomics_on_data_and_no_whole_cache_write_back(ordered_kernels):
+    for name, body in ordered_kernels.items():
+        assert not any("atomic" in t for t in body), name
+        assert not any(_is("buffer_wbl2", t) for t in body), name      # slots go out with sc1 stores, not by writing the L2 back
