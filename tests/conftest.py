@@ -66,6 +66,8 @@ _TIERS = [
          "test_f32_stream_k_", "tests/test_gpu_fuzz.py", "test_race_screen_", "tests/test_gpu_streamk_stress.py")),
     # tier 9: self-imposed guards
     (9, ("test_throughput_floor_",)),
+    # tier 10: the one test whose failure mode is a hung GPU (run in a child process under a watchdog; still: nothing after it)
+    (10, ("test_cu_masked_stream_",)),
 ]
 # a tier-7/9 pattern wins over a file-level pattern of an earlier tier (the soak lives in test_gpu_capi.py)
 _LATE_FIRST = sorted(_TIERS, key=lambda t: -t[0])
