@@ -2,7 +2,7 @@
 `extract_benchmarks` (:578-669) -- run `RunHardware N K M hw off` per configuration, find
 `([\\d\\.]+) seconds[^\\d]+([\\d\\.]+) GOp/s` (:601-602) in its output, write a CSV row.  tools/benchmark.py is this
 repo's driver with that contract; here it runs on the GPU over its quick configurations (the BASELINE configs' types and
-operators at 2048^3) and every row is checked against the reference's own regex and arithmetic."""
+operators at 8192^3) and every row is checked against the reference's own regex and arithmetic."""
 import csv
 import os
 import re

@@ -28,7 +28,10 @@ BASELINE_CONFIGS = [  # BASELINE.json configs that fit one GPU
     ("float", "Add", "Min", 8192, 8192, 8192),
     ("float", "Multiply", "Add", 16384, 16384, 16384, {"MM_PATH": "split"}),  # the opt-in fp32 path on the bf16 matrix cores
 ]
-QUICK_CONFIGS = [(t, m, r, 2048, 2048, 2048, *rest) for (t, m, r, _n, _k, _m, *rest) in BASELINE_CONFIGS]
+# quick: 8192^3 -- not smaller: the runner prints the time like the reference does (default ostream format), which turns to
+# scientific notation below 1e-4 s, and the reference's regex then picks up the exponent's digits (a 2048^3 half product
+# takes 3.4e-05 s).  The reference's own runs are seconds long; the contract is kept as it is.
+QUICK_CONFIGS = [(t, m, r, 8192, 8192, 8192, *rest) for (t, m, r, _n, _k, _m, *rest) in BASELINE_CONFIGS]
 
 
 def main():
