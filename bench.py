@@ -59,13 +59,17 @@ PATHS = {"float_split": 2}  # workload -> mm_path_t (default MM_PATH_AUTO)
 DTYPE_TAG = {"float": "f32", "half": "f16 (f32 accumulate)", "double": "f64", "uint8_t": "u8 (i32 accumulate)"}
 # Context for the two power-limited workloads (not a roof this file prices against: `peak` stays the
 # guide's dense MFMA peak): what the matrix cores sustain from registers alone, no LDS and no memory, on
-# different random operands per MFMA at this board's power limit (tools/probes/probe_mfma_rate.hip).
+# different random operands per MFMA at this board's power limit -- for the instruction the SHIPPED kernel issues
+# (v_mfma_f32_16x16x32_f16 / v_mfma_i32_16x16x64_i8 over the kernel's 128 x 64 wavefront tile, two waves per SIMD:
+# tools/probes/probe_mfma_power.hip).  Round 2's figures for the retired 32x32 forms were 1778 / 3532.
 POWER_CEILING = {
-    "half": {"register_only_mfma_on_random_operands_TOps": 1778.0, "clock_GHz": 1.70,
-             "source": "profiles/r02s_probe_mfma_issue_rates_and_power_ceiling.txt"},
-    "uint8_t": {"register_only_mfma_on_random_operands_TOps": 3532.0, "clock_GHz": 1.68,
-                "source": "profiles/r02s_probe_mfma_issue_rates_and_power_ceiling.txt"},
+    "half": {"register_only_mfma_on_random_operands_TOps": 2060.0, "clock_GHz": 1.98, "instruction": "v_mfma_f32_16x16x32_f16",
+             "source": "profiles/r03b_probe_mfma_power_by_shape_and_operand_order.txt"},
+    "uint8_t": {"register_only_mfma_on_random_operands_TOps": 4090.0, "clock_GHz": 1.97, "instruction": "v_mfma_i32_16x16x64_i8",
+                "source": "profiles/r03b_probe_mfma_power_by_shape_and_operand_order.txt"},
 }
+# MM_PATH_SPLIT runs v_mfma_f32_32x32x16_bf16 (same probe file)
+SPLIT_BF16_REGISTER_ONLY_TOPS = 1930.0
 
 
 # What a loop of nothing but independent MFMAs on registers sustains on this part (same probe, constant operands):
@@ -181,11 +185,11 @@ def attach_replayed(roofline, kernel_name, shape):
     return roofline
 
 
-def timed_steps(g, torch, a, b, c, dtype, map_op, reduce_op, steps, warmup, barrier, path=0):
+def timed_steps(g, torch, a, b, c, dtype, map_op, reduce_op, steps, warmup, barrier, path=0, transposed_a=False):
     """W untimed steps, barrier + synchronize, EXACTLY `steps` steps, synchronize + barrier.
     Returns (wall seconds of the timed region, sorted per-launch ms from events on the launch stream)."""
     def step():
-        g.matmul(a, b, dtype, map_op, reduce_op, path=path, out=c)
+        g.matmul(a, b, dtype, map_op, reduce_op, path=path, transposed_a=transposed_a, out=c)
     for _ in range(warmup):
         step()
     torch.cuda.synchronize()
@@ -232,32 +236,41 @@ def roofline_obj(dtype, roof, peak, rows, k, m, launch_ms):
 def extra_workloads(g, torch, dev, local_rank, steps=5):
     """The other single-GPU BASELINE configs, a few steps each, in the same process."""
     out = []
+    # half_kxn / uint8_kxn (round 4, for one round): the same problems with A handed over K x N (MM_TRANSPOSED_A,
+    # kernel/Memory.cpp:205-261) -- a transposition pre-pass inside the timed step, then the row-major default
     jobs = [("half", None), ("double", None), ("minplus", None), ("minplus_f64", None), ("uint8", None), ("float", C5A_ROWS),
-            ("float_split", None)]
+            ("float_split", None), ("half_kxn", None), ("uint8_kxn", None)]
     for key, rows_override in jobs:
-        dtype, map_op, reduce_op, size, roof, peak = WORKLOADS[key]
+        kxn = key.endswith("_kxn")
+        dtype, map_op, reduce_op, size, roof, peak = WORKLOADS[key[:-4] if kxn else key]
         rows = rows_override or size
         k = m = size
         try:
             a, b, c = alloc_fill(g, torch, dev, local_rank, dtype, rows, k, m, 2000 + len(out), 3000 + len(out))
+            if kxn:
+                a = a.view(k, rows)      # the same HBM bytes read as a K x N matrix (rows == k here)
             path = PATHS.get(key, 0)
-            elapsed, launch_ms = timed_steps(g, torch, a, b, c, dtype, map_op, reduce_op, steps, 2, lambda: None, path)
+            elapsed, launch_ms = timed_steps(g, torch, a, b, c, dtype, map_op, reduce_op, steps, 2, lambda: None, path, kxn)
             value = 1e-9 * 2.0 * rows * k * m * steps / elapsed
             entry = {"workload": f"{dtype} {rows}x{k}x{m} ({map_op},{reduce_op}) on 1 MI355X"
-                                 + ("; BASELINE configs[4]'s job without the split" if rows_override else ""),
-                     "kernel": g.kernel_name(g.make_config(dtype, map_op, reduce_op, path), rows, k, m),
+                                 + ("; BASELINE configs[4]'s job without the split" if rows_override else "")
+                                 + ("; A stored K x N (MM_TRANSPOSED_A): transposition pre-pass + row-major kernel, both inside the timed step" if kxn else ""),
+                     "kernel": g.kernel_name(g.make_config(dtype, map_op, reduce_op, path, kxn), rows, k, m),
                      "dtype": DTYPE_TAG[dtype], "value": round(value, 1), "unit": "GOp/s", "steps": steps, "warmup": 2,
                      "ms_per_step": round(1e3 * elapsed / steps, 4),
                      "roofline": roofline_obj(dtype, roof, peak, rows, k, m, launch_ms)}
-            attach_replayed(entry["roofline"], entry["kernel"], (rows, k, m))
+            if kxn:
+                entry["roofline"]["traffic_note"] = "two kernels per step (transposition pre-pass + product): no single kernel's counters apply"
+            else:
+                attach_replayed(entry["roofline"], entry["kernel"], (rows, k, m))
             if key in VALU_SUSTAINED:
                 entry["roofline"]["valu_sustained"] = VALU_SUSTAINED[key]
             if key == "float_split":
                 entry["workload"] += "; MM_PATH_SPLIT (opt-in), split + re-tile pre-pass inside the timed step"
                 entry["dtype"] = "f32 in/out; operands as 3 bf16 planes, 6 bf16 MFMA products per pair, f32 accumulate"
                 entry["roofline"].pop("mfma_sustained", None)   # that figure is the fp32 MFMA's; this kernel runs on the bf16 one
-                entry["roofline"]["power_ceiling"] = {"register_only_bf16_mfma_on_random_operands_TOps_div_6": round(1778.0 / 6.0, 1),
-                                                      "source": POWER_CEILING["half"]["source"]}
+                entry["roofline"]["power_ceiling"] = {"register_only_bf16_mfma_on_random_operands_TOps_div_6": round(SPLIT_BF16_REGISTER_ONLY_TOPS / 6.0, 1),
+                                                      "instruction": "v_mfma_f32_32x32x16_bf16", "source": POWER_CEILING["half"]["source"]}
                 entry["roofline"]["peak_note"] = ("bf16 dense MFMA peak 2500 TFLOP/s / 6 MFMAs per fp32 multiply-add block; "
                                                   "against the fp32 MFMA peak (157.3) the same number is "
                                                   f"{round(entry['roofline']['achieved'] / 157.3, 3)}")
@@ -448,6 +461,14 @@ def main():
                 "roofline": roofline_obj(dtype, roof, peak, w_rows, k, m, w_launch)}
         if world == 1 and headline and not args.no_extra:
             out["workloads"] = extra_workloads(g, torch, dev, local_rank)
+            # the strong-scaling job (BASELINE configs[4], float 65536 x 16384 x 16384) on ONE GPU, already timed above:
+            # an N = G line's value / scale_base.value is the strong-scaling factor of that job without a second run
+            for w in out["workloads"]:
+                if w.get("roofline") and w["workload"].startswith(f"float {C5A_ROWS}x{SIZE}x{SIZE} "):
+                    out["scale_base"] = {"workload": w["workload"], "value": w["value"], "unit": w["unit"], "n_gpus": 1,
+                                         "steps": w["steps"], "warmup": w["warmup"], "ms_per_step": w["ms_per_step"],
+                                         "note": "the job `bench.py --gpus G` (scaling strong) splits along N, run unsplit on this GPU: "
+                                                 "strong-scaling factor at G = that line's value / this value"}
         if world == 1 and not args.no_cpu_baseline and headline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

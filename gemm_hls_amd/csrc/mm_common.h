@@ -119,6 +119,9 @@ const char *mfma_i8_name(const Problem &p);
 int mfma_f32_auto_variant(const Problem &p);
 int mfma_f64_tile(const Problem &p);  // 0: 256x128, 1: 128x128
 int mfma_f16_tile(const Problem &p);  // 0: 256x256, 4: 128x256  // shape-adaptive pick (variant < 0)
+// dst[n][k] = src[k][n] for 1- and 2-byte elements (mm_transpose.hip); N and K multiples of 16 bytes' worth of elements
+int launch_transpose_kxn(hipStream_t s, const void *src, void *dst, unsigned K, unsigned N, unsigned elem_size);
+bool transposes_first_small(const Problem &p, unsigned elem_size);   // K x N A of half / int8: pre-pass + the row-major default
 int launch_fill(hipStream_t s, mm_dtype_t dtype, void *ptr, size_t elements, unsigned long long seed);
 
 constexpr int kErrNotSupported = 801;  // hipErrorNotSupported

@@ -872,10 +872,20 @@ int mfma_f16_tile(const Problem &p) {  // 0: 256x256, 4: 128x256, 5: 64x256
 // both go through it.  f16_variant: -1 the best the shape allows; 0 slab64; 4 / 5 slab64 on the 128 x 256 / 64 x 256 tile;
 // 11 pingpong_k32; 100 pingpong_32x32x16; 200 pingpong_16x16x32.  A pinned kernel that cannot serve the shape falls
 // through to the next one down (as the default does), so a knob never turns a servable problem into an error.
+// K x N A (MM_TRANSPOSED_A) of a wide problem under the shape-adaptive pick: transposed into a stream-ordered workspace
+// first (mm_transpose.hip), then the row-major default with its bits.  A pinned f16_variant keeps the K x N kernels.
+static bool transposes_first(const Problem &p) {
+  if (tuning(TUNE_F16_VARIANT) >= 0 || !transposes_first_small(p, 2)) return false;
+  Problem q = p;
+  q.a_transposed = false;
+  return pp64_serves(q) && mfma_f16_tile(q) == 0;
+}
+
 static Kind resolve(const Problem &p) {
   if (!mfma_f16_serves(p)) return K_NONE;
   const int v = tuning(TUNE_F16_VARIANT);
   if (!(v < 0 || v == 0 || v == 4 || v == 5 || v == 11 || v == 100 || v == 200)) return K_NONE;   // lab ids are not in this library
+  if (transposes_first(p)) return K_PP16;
   if (p.a_transposed) return (v != 0 && ppk32_serves(p)) ? K_PPK32_AT : K_SLAB64_AT;
   if (v == 5 || (v < 0 && mfma_f16_tile(p) == 5)) return K_SLAB64_64;
   if (v == 4 || (v < 0 && mfma_f16_tile(p) == 4)) return K_SLAB64_128;
@@ -900,6 +910,24 @@ static int launch_tile(hipStream_t s, const Problem &p, Kern kern, unsigned bm, 
 
 int launch_mfma_f16(hipStream_t s, const Problem &p) {
   static unsigned long long cfg[K_NONE] = {};
+  if (transposes_first(p)) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    hipMemPool_t pool = nullptr;
+    if (int rc = workspace_pool(dev, &pool)) return rc;
+    void *an = nullptr;
+    if ((e = hipMallocFromPoolAsync(&an, (size_t)p.n * p.k * 2, pool, s)) != hipSuccess) return (int)e;
+    int rc = launch_transpose_kxn(s, p.a, an, p.k, p.n, 2);
+    if (rc == 0) {
+      Problem q = p;
+      q.a = an;
+      q.a_transposed = false;
+      rc = launch_mfma_f16(s, q);
+    }
+    const hipError_t f = hipFreeAsync(an, s);
+    return rc ? rc : (int)f;
+  }
   const Kind k = resolve(p);
   switch (k) {
     case K_PP16: return launch_tile(s, p, mfma_f16_pp2s_kernel, 256, 256, GeoPP2::THREADS, GeoPP2::LDS_BYTES, cfg[k]);

@@ -769,10 +769,19 @@ static int mfma_i8_tile(const Problem &p) {  // 0: 256x256, 5: 64x256
 // i8_variant: -1 the best the shape allows; 0 slab128; 5 slab128 on the 64 x 256 tile; 10 pingpong_k64; 100 pingpong_32x32x32;
 // 200 pingpong_16x16x64 (one resolver for mm_kernel_name and the launcher; a pinned kernel that cannot serve the shape
 // falls through).
+// K x N A of a wide problem under the shape-adaptive pick: transposition pre-pass (mm_transpose.hip), then the row-major default
+static bool transposes_first(const Problem &p) {
+  if (tuning(TUNE_I8_VARIANT) >= 0 || !transposes_first_small(p, 1)) return false;
+  Problem q = p;
+  q.a_transposed = false;
+  return pp128_serves(q) && mfma_i8_tile(q) == 0;
+}
+
 static Kind resolve(const Problem &p) {
   if (!mfma_i8_serves(p)) return K_NONE;
   const int v = tuning(TUNE_I8_VARIANT);
   if (!(v < 0 || v == 0 || v == 5 || v == 10 || v == 100 || v == 200)) return K_NONE;   // lab ids are not in this library
+  if (transposes_first(p)) return K_PP16;
   if (p.a_transposed) return (v != 0 && ppk64_serves(p)) ? K_PPK64_AT : K_SLAB128_AT;
   if (v == 5 || (v < 0 && mfma_i8_tile(p) == 5)) return K_SLAB128_64;
   if (v == 0) return K_SLAB128;
@@ -796,6 +805,24 @@ static int launch_tile(hipStream_t s, const Problem &p, Kern kern, unsigned thre
 
 int launch_mfma_i8(hipStream_t s, const Problem &p) {
   static unsigned long long cfg[K_NONE] = {};
+  if (transposes_first(p)) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    hipMemPool_t pool = nullptr;
+    if (int rc = workspace_pool(dev, &pool)) return rc;
+    void *an = nullptr;
+    if ((e = hipMallocFromPoolAsync(&an, (size_t)p.n * p.k, pool, s)) != hipSuccess) return (int)e;
+    int rc = launch_transpose_kxn(s, p.a, an, p.k, p.n, 1);
+    if (rc == 0) {
+      Problem q = p;
+      q.a = an;
+      q.a_transposed = false;
+      rc = launch_mfma_i8(s, q);
+    }
+    const hipError_t f = hipFreeAsync(an, s);
+    return rc ? rc : (int)f;
+  }
   const Kind k = resolve(p);
   switch (k) {
     case K_PP16: return launch_tile(s, p, mfma_i8_pp2s_kernel, GeoI8PP2::THREADS, GeoI8PP2::LDS_BYTES, cfg[k]);

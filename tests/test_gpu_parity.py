@@ -567,6 +567,43 @@ def test_f16_i8_transposed_a_on_the_pingpong_schedule(dtype, shape):
         assert np.array_equal(c_at, _oracle.naive(dtype, "Multiply", "Add", a, b))
 
 
+@pytest.mark.parametrize("dtype,shape,kernel", [("half", (1032, 576, 12296), "mfma_f16_256x256_pingpong_16x16x32"),
+                                                ("half", (2048, 256, 16384), "mfma_f16_256x256_pingpong_16x16x32"),
+                                                ("uint8_t", (1040, 640, 12304), "mfma_i8_256x256_pingpong_16x16x64"),
+                                                ("int8_t", (2048, 512, 16384), "mfma_i8_256x256_pingpong_16x16x64")],
+                         ids=lambda v: "x".join(map(str, v)) if isinstance(v, tuple) else str(v))
+def test_f16_i8_wide_kxn_problems_are_transposed_first_and_keep_the_row_major_bits(dtype, shape, kernel):
+    """Round 4: a K x N A (MM_TRANSPOSED_A, kernel/Memory.cpp:205-261) of a wide problem (M >= 12288) goes through a
+    transposition pre-pass into the library's workspace and then runs the row-major default kernel (the K x N kernels
+    need twice the LDS gather instructions and run 6-10 % behind).  Ragged N / M tiles included.  Bits: the row-major
+    call's, exactly; a pinned variant keeps the K x N kernel, whose bits are the same as well."""
+    n, k, m = shape
+    rng = np.random.default_rng(n + m)
+    if dtype == "half":
+        a = rng.uniform(-1, 2, size=(n, k)).astype(np.float16)
+        b = rng.uniform(-1, 2, size=(k, m)).astype(np.float16)
+    else:
+        npdt = np.uint8 if dtype == "uint8_t" else np.int8
+        a = rng.integers(np.iinfo(npdt).min, np.iinfo(npdt).max + 1, size=(n, k)).astype(npdt)
+        b = rng.integers(np.iinfo(npdt).min, np.iinfo(npdt).max + 1, size=(k, m)).astype(npdt)
+    at = np.ascontiguousarray(a.T)
+    assert g.kernel_name(g.make_config(dtype, transposed_a=True), n, k, m) == kernel
+    c_row, _ = g.matmul_capi(a, b, dtype)
+    c_kxn, _ = g.matmul_capi(at, b, dtype, transposed_a=True)
+    assert np.array_equal(c_row.view(np.uint8), c_kxn.view(np.uint8))
+    knob = "f16_variant" if dtype == "half" else "i8_variant"
+    try:
+        g.set_tuning(knob, 11 if dtype == "half" else 10)
+        assert "KxN" in g.kernel_name(g.make_config(dtype, transposed_a=True), n, k, m)
+        c_pinned, _ = g.matmul_capi(at, b, dtype, transposed_a=True)
+    finally:
+        g.set_tuning(knob, -1)
+    assert np.array_equal(c_row.view(np.uint8), c_pinned.view(np.uint8))
+    if dtype != "half":
+        want = (a[:32].astype(np.int64) @ b.astype(np.int64)).astype(a.dtype)       # wraps like Data_t
+        assert np.array_equal(c_row[:32], want)
+
+
 def test_f16_overflow_behaviour_matches_ieee():
     # K large enough that sums pass 65504: binary16 result is +inf, like a correctly rounded result
     n, k, m = 33, 4096, 64

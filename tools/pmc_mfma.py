@@ -20,7 +20,7 @@ PASSES = [
     ["TCC_HIT_sum", "TCC_MISS_sum"],
     ["SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_VMEM", "SQ_INSTS_VALU", "SQ_INSTS_LDS"],
 ]
-KERNEL = {"f32": "mfma_f32_", "f64": "mfma_f64_kernel", "f16": "mfma_f16_", "minplus": "valu_tile_",
+KERNEL = {"f32": "mfma_f32_", "f64": "mfma_f64_kernel", "f16": "mfma_f16_", "minplus": "valu_tile_", "minplus_f64": "valu_tile_",
           "uint8": "mfma_i8_", "split": "mfma_f32_split_kernel"}
 VARIANT = None  # --variant: pins the family's tuning knob (sweep.py --variants) for every pass
 
@@ -59,7 +59,7 @@ def dispatched_kernel_name(what, size, variant):
     """mm_kernel_name() of the launch the passes profile (asked in a child process: the knob is process state)."""
     table = {"f32": ("float", "Multiply", "Add", "f32_variant", 0), "f16": ("half", "Multiply", "Add", "f16_variant", 0),
              "f64": ("double", "Multiply", "Add", "f64_variant", 0), "uint8": ("uint8_t", "Multiply", "Add", "i8_variant", 0),
-             "minplus": ("float", "Add", "Min", "valu_variant", 0), "split": ("float", "Multiply", "Add", "split_variant", 2)}
+             "minplus": ("float", "Add", "Min", "valu_variant", 0), "minplus_f64": ("double", "Add", "Min", "valu_variant", 0), "split": ("float", "Multiply", "Add", "split_variant", 2)}
     dtype, mp, rd, knob, path = table[what]
     code = ("import gemm_hls_amd as g\n"
             f"v = {variant!r}\n"

@@ -23,7 +23,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 WHAT = {"f32": ("mfma_f32_kernel", 4, "float"), "f16": ("mfma_f16_", 2, "half"), "f64": ("mfma_f64_kernel", 8, "double"),
-        "uint8": ("mfma_i8_", 1, "uint8_t"), "minplus": ("valu_tile_", 4, "float (Add,Min)"),
+        "uint8": ("mfma_i8_", 1, "uint8_t"), "minplus": ("valu_tile_", 4, "float (Add,Min)"), "minplus_f64": ("valu_tile_", 8, "double (Add,Min)"),
         "split": ("mfma_f32_split_kernel", 4, "float via MM_PATH_SPLIT (GEMM kernel only; the pre-pass moves 10 B per element of A and B on top)")}
 
 
@@ -57,7 +57,7 @@ def dispatched_kernel_name(what, size, variant):
     """mm_kernel_name() of the launch the passes profile (asked in a child process: the knob is process state)."""
     table = {"f32": ("float", "Multiply", "Add", "f32_variant", 0), "f16": ("half", "Multiply", "Add", "f16_variant", 0),
              "f64": ("double", "Multiply", "Add", "f64_variant", 0), "uint8": ("uint8_t", "Multiply", "Add", "i8_variant", 0),
-             "minplus": ("float", "Add", "Min", "valu_variant", 0), "split": ("float", "Multiply", "Add", "split_variant", 2)}
+             "minplus": ("float", "Add", "Min", "valu_variant", 0), "minplus_f64": ("double", "Add", "Min", "valu_variant", 0), "split": ("float", "Multiply", "Add", "split_variant", 2)}
     dtype, mp, rd, knob, path = table[what]
     code = ("import gemm_hls_amd as g\n"
             f"v = {variant!r}\n"

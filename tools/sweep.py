@@ -39,7 +39,7 @@ def time_config(dtype, mp, rd, n, k, m, reps, path=g.PATH_AUTO):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["f32", "f64", "f16", "minplus", "uint8", "split", "all"])
+    ap.add_argument("what", choices=["f32", "f64", "f16", "minplus", "minplus_f64", "uint8", "split", "all"])
     ap.add_argument("--sizes", default="4096,8192,16384")
     ap.add_argument("--variants", default="")
     ap.add_argument("--reps", type=int, default=5)
@@ -87,8 +87,8 @@ def main():
                       f"({100*tf/PEAK['float']:5.1f}% of 157.3)  best {2.0*s**3/best/1e12:7.2f} TF", flush=True)
     else:
         table = {"f64": ("double", "Multiply", "Add"), "f16": ("half", "Multiply", "Add"),
-                 "minplus": ("float", "Add", "Min"), "uint8": ("uint8_t", "Multiply", "Add")}
-        knob = {"f64": "f64_variant", "f16": "f16_variant", "uint8": "i8_variant", "minplus": "valu_variant"}
+                 "minplus": ("float", "Add", "Min"), "minplus_f64": ("double", "Add", "Min"), "uint8": ("uint8_t", "Multiply", "Add")}
+        knob = {"f64": "f64_variant", "f16": "f16_variant", "uint8": "i8_variant", "minplus": "valu_variant", "minplus_f64": "valu_variant"}
         for key in ([args.what] if args.what != "all" else list(table)):
             dtype, mp, rd = table[key]
             variants = [int(v) for v in args.variants.split(",")] if (args.variants and key in knob) else [-1]
