@@ -91,9 +91,9 @@ mm_config_t default_cfg() {
 std::once_flag g_tuning_once;
 std::atomic<int> g_tuning[mm::TUNE_COUNT];
 const char *const kTuneName[mm::TUNE_COUNT] = {"f32_variant", "f64_variant", "f16_variant", "i8_variant", "band_rows",
-                                               "valu_variant", "split_variant", "f32_splitk", "ablations", "debug_poison"};
+                                               "valu_variant", "split_variant", "f32_splitk", "ablations", "debug_poison", "kxn_prepass_min_m"};
 const char *const kTuneEnv[mm::TUNE_COUNT] = {"MM_F32_VARIANT", "MM_F64_VARIANT", "MM_F16_VARIANT", "MM_I8_VARIANT",
-                                              "MM_BAND_ROWS", "MM_VALU_VARIANT", "MM_SPLIT_VARIANT", "MM_F32_SPLITK", "MM_ABLATIONS", "MM_DEBUG_POISON"};
+                                              "MM_BAND_ROWS", "MM_VALU_VARIANT", "MM_SPLIT_VARIANT", "MM_F32_SPLITK", "MM_ABLATIONS", "MM_DEBUG_POISON", "MM_KXN_PREPASS_MIN_M"};
 void tuning_init() {
   for (int i = 0; i < mm::TUNE_COUNT; ++i) {
     const char *e = getenv(kTuneEnv[i]);

@@ -156,6 +156,7 @@ enum Tunable {
                          //                 measurements; they produce WRONG results and are refused otherwise)
   TUNE_DEBUG_POISON,     // MM_DEBUG_POISON 1 = fill scratch the kernels hand data through (stream-K slots) with NaN before
                          //                 every launch: a read of anything this launch did not write shows up in C
+  TUNE_KXN_PREPASS_MIN_M,  // MM_KXN_PREPASS_MIN_M  half / int8 with a K x N A: M from which the transposition pre-pass is taken (-1: 6144)
   TUNE_COUNT
 };
 int tuning(Tunable t);  // mm_capi.hip

@@ -1232,6 +1232,16 @@ int mfma_f32_auto_variant(const Problem &p) {
   if (knob < 0 && streamk_wins(p)) return 35;   // the 128 x 128 geometry is the one stream-K runs on
   const int v = pick_tile(kAutoCands, 3, p.n, p.m);
   if (v == 35 && (knob < 0 || knob == 1) && small_wins(p)) return 64;   // (a forced split or stream-K means the 128 x 128 geometry)
+  // Round 4, decided by energy.  Where the problem is whole rounds of 256 x 256 tiles, the two big
+  // geometries are within 1 % of each other in steady state (float 16384^3: 151.29 vs 150.72 TF, 20 launches back to back,
+  // alternating in one process: profiles/r04c_f32_default_ab_steady_state.txt), but the 256 x 256 one draws 4.6 % less board
+  // power for it (1135 W against 1188 W, 128.5 against 122.8 GFLOP/s/W: profiles/r04b_f32_energy_33_vs_8.txt) and pulls half
+  // the bytes through the fabric (33.5 GB against 72 GB per launch) -- eight boards of that on the node this is meant
+  // for.  Same bits either way (the shipped geometries issue the same MFMAs per output element in the same order).
+  if (v == 33) {
+    const unsigned long long t256 = (unsigned long long)((p.n + 255) / 256) * ((p.m + 255) / 256);
+    if (t256 % 256 == 0 && t256 >= 4 * 256) return 8;
+  }
   return v;
 }
 

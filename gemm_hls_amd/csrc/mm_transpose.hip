@@ -3,7 +3,9 @@
 // LDS with twice the transpose-read instructions of a row-major one (24 instead of 16 LDS reads per wavefront and slab:
 // every operand of v_mfma_*_16x16x* wants consecutive k of one row) and run 6-10 % behind the row-major kernels at every
 // size.  The pre-pass moves N x K elements once in and once out -- O(N K) against the product's O(N K M) -- so for wide
-// enough M it costs less than that: at M = 16384 about 4-5 % of the product, at 32768 half of that.
+// enough M it costs less than that: measured 3.5 % of the product at M = 16384, 2.2 % at 32768, 5 % at 6144-8192 for
+// half (uint8: 3.4 / 2.1 / 8-11 %), against the K x N kernels' 7-15 % (profiles/r04b_kxn_prepass.txt,
+// r04c_kxn_prepass_forced_small_m.txt); at 4096 the pass costs more than it returns.
 // The product then runs the row-major default and gives ITS bits: a K x N call equals the row-major call.
 //
 // dst[n][k] = src[k][n], 128-byte x 128-byte element tiles through LDS: 16-byte loads along n (one request per line),
@@ -62,9 +64,11 @@ int launch_transpose_kxn(hipStream_t s, const void *src, void *dst, unsigned K, 
 }
 
 // K x N A through the pre-pass: worth it where the row-major default kernel serves the transposed problem and M is wide
-// enough for the O(N K) pass to cost less than the K x N kernel's deficit (measured 6-10 % half, 8-9 % int8).
+// enough for the O(N K) pass to cost less than the K x N kernel's deficit: from M = 6144 (kxn_prepass_min_m overrides).
 bool transposes_first_small(const Problem &p, unsigned elem_size) {
-  return p.a_transposed && p.m >= 12288 && p.n >= 1024 && (unsigned long long)p.n * p.k * elem_size <= (4ull << 30);
+  const int knob = tuning(TUNE_KXN_PREPASS_MIN_M);
+  const unsigned min_m = knob >= 0 ? (unsigned)knob : 6144u;   // measured: profiles/r04c_kxn_prepass_forced_small_m.txt
+  return p.a_transposed && p.m >= min_m && p.n >= 1024 && (unsigned long long)p.n * p.k * elem_size <= (4ull << 30);
 }
 
 }  // namespace mm

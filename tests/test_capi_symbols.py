@@ -109,7 +109,7 @@ def test_tuning_knobs_are_library_state_not_environment(monkeypatch):
         assert g.kernel_name(g.make_config("float"), 4096, 4096, 4096) == "mfma_f32_256x256x16_w8"
     finally:
         g.set_tuning("f32_variant", -1)
-    assert g.kernel_name(g.make_config("float"), 16384, 16384, 16384) == "mfma_f32_128x256x16_w4x2_flush4096"
+    assert g.kernel_name(g.make_config("float"), 16384, 16384, 16384) == "mfma_f32_256x256x16_w8_flush4096"
     with pytest.raises(g.MMError, match="unknown tuning knob"):
         g.set_tuning("no_such_knob", 1)
 
@@ -140,7 +140,9 @@ def test_f32_variant_ids_of_the_product():
 
 def test_kernel_info_binding():
     info = g.kernel_info(g.make_config("float"), 16384, 16384, 16384)
-    assert (info.tile_n, info.tile_m, info.tile_k, info.wavefronts) == (128, 256, 16, 4)   # two such workgroups per CU
+    assert (info.tile_n, info.tile_m, info.tile_k, info.wavefronts) == (256, 256, 16, 8)   # whole rounds of 256 x 256 tiles (round 4)
+    mid = g.kernel_info(g.make_config("float"), 4096, 4096, 4096)
+    assert (mid.tile_n, mid.tile_m, mid.tile_k, mid.wavefronts) == (128, 256, 16, 4)        # one round: two such workgroups per CU
     small = [g.kernel_info(g.make_config(t), 512, 512, 512) for t in ("float", "double", "half", "uint8_t")]   # the small-problem geometries (round 3)
     assert [(i.tile_n, i.tile_m, i.tile_k, i.wavefronts) for i in small] == [(64, 64, 32, 4), (64, 64, 16, 4), (64, 256, 64, 4), (64, 256, 128, 4)]
     assert info.compute_units == 256 and info.max_clock_mhz == 2400.0
@@ -168,14 +170,27 @@ DISPATCH_TABLE = [
     ("float", (2816, 2816, 2816), False, "mfma_f32_128x256x16_w4x2_flush4096"),     # whole tiles fit
     ("float", (4096, 4096, 4096), False, "mfma_f32_128x256x16_w4x2_flush4096"),
     ("float", (6144, 6144, 6144), False, "mfma_f32_128x128x32_w4x2_flush4096"),
-    ("float", (8192, 8192, 8192), False, "mfma_f32_128x256x16_w4x2_flush4096"),
-    ("float", (16384, 16384, 16384), False, "mfma_f32_128x256x16_w4x2_flush4096"),  # BASELINE configs[1]
-    ("float", (65536, 16384, 16384), False, "mfma_f32_128x256x16_w4x2_flush4096"),  # BASELINE configs[2]
+    # round 4: >= 4 whole rounds of 256 x 256 tiles take that geometry -- within 1 % of the 128 x 256 one in steady state, 4.6 %
+    # less board power, half the fabric traffic (profiles/r04b_f32_energy_33_vs_8.txt, r04c_f32_default_ab_steady_state.txt)
+    ("float", (8192, 8192, 8192), False, "mfma_f32_256x256x16_w8_flush4096"),
+    ("float", (16384, 16384, 16384), False, "mfma_f32_256x256x16_w8_flush4096"),    # BASELINE configs[1]
+    ("float", (65536, 16384, 16384), False, "mfma_f32_256x256x16_w8_flush4096"),    # BASELINE configs[4], unsplit
+    ("float", (8192, 16384, 16384), False, "mfma_f32_256x256x16_w8_flush4096"),     # ... and its row slab on 8 GPUs
+    ("float", (12288, 4096, 8192), False, "mfma_f32_256x256x16_w8_flush4096"),      # 48 x 32 tiles = 6 rounds
     ("float", (1024, 1024, 1024), True, "mfma_f32_64x64x32_w4x2_flush4096"),        # K x N A outside whole rounds: transposed first,
     ("float", (2048, 2048, 2048), True, "mfma_f32_128x128x32_w4x2_flush4096"),      #   then the row-major rules
     ("float", (6144, 6144, 6144), True, "mfma_f32_128x128x32_w4x2_flush4096"),
     ("float", (4096, 4096, 4096), True, "mfma_f32_256x256x16_w8_flush4096"),        # whole rounds: the K x N kernel itself
     ("float", (16384, 16384, 16384), True, "mfma_f32_256x256x16_w8_flush4096"),
+    # round 4: half / int8 with a K x N A and M >= 6144: transposition pre-pass, then the row-major default
+    # (profiles/r04b_kxn_prepass.txt, r04c_kxn_prepass_forced_small_m.txt); below that the K x N ping-pong kernels
+    ("half", (16384, 16384, 16384), True, "mfma_f16_256x256_pingpong_16x16x32"),
+    ("half", (32768, 32768, 32768), True, "mfma_f16_256x256_pingpong_16x16x32"),
+    ("half", (6144, 6144, 6144), True, "mfma_f16_256x256_pingpong_16x16x32"),
+    ("half", (4096, 4096, 4096), True, "mfma_f16_256x256_pingpong_k32_KxN"),
+    ("uint8_t", (32768, 32768, 32768), True, "mfma_i8_256x256_pingpong_16x16x64"),
+    ("uint8_t", (8192, 8192, 8192), True, "mfma_i8_256x256_pingpong_16x16x64"),
+    ("uint8_t", (4096, 4096, 4096), True, "mfma_i8_256x256_pingpong_k64_KxN"),
     ("double", (1024, 1024, 1024), False, "mfma_f64_64x64x16_w4x4"),
     ("double", (3072, 3072, 3072), False, "mfma_f64_64x64x16_w4x4"),
     ("double", (1792, 1792, 1792), False, "mfma_f64_128x128x16_w4x2"),

@@ -308,7 +308,7 @@ def test_f32_rows_of_c_longer_than_the_32_bit_reach_of_the_interior_write_back()
 
 
 @pytest.mark.parametrize("dtype,ops,size,floor_tops,kernel", [
-    ("float", ("Multiply", "Add"), 16384, 0.92 * 157.3, "mfma_f32_128x256x16_w4x2_flush4096"),   # measured 151.4-152.6 across boxes
+    ("float", ("Multiply", "Add"), 16384, 0.92 * 157.3, "mfma_f32_256x256x16_w8_flush4096"),     # measured 150.2-150.8 (the 128 x 256 geometry: 151.2-152.6) across boxes
     ("double", ("Multiply", "Add"), 16384, 0.92 * 78.6, "mfma_f64_256x128x16_w8"),               # measured 75.7-76.4
     ("half", ("Multiply", "Add"), 32768, 1250.0, "mfma_f16_256x256_pingpong_16x16x32"),          # measured 1.44-1.51 PF (power-limited: box-dependent)
     ("float", ("Add", "Min"), 8192, 0.75 * 78.6, "valu_tile"),                                   # measured 65-75 TOp/s (cold / warm box)

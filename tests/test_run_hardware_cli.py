@@ -89,7 +89,7 @@ def test_run_hardware_verifies_on_gpu(exe, shape, mode):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("exe,shape,kernel", [
-    ("RunHardware.exe", (16384, 16384, 16384), "mfma_f32_128x256x16_w4x2_flush4096"),                    # BASELINE configs[1]
+    ("RunHardware.exe", (16384, 16384, 16384), "mfma_f32_256x256x16_w8_flush4096"),                      # BASELINE configs[1]
     ("RunHardware_double_Multiply_Add.exe", (16384, 16384, 16384), "mfma_f64_256x128x16_w8"),           # configs[3]
     ("RunHardware_float_Add_Min.exe", (8192, 8192, 8192), "valu_tile"),                                 # configs[4], min-plus
 ])
@@ -207,9 +207,12 @@ def test_print_specifications_cli_and_model():
     out = r.stdout
     assert "Number of operations: 8796093022208" in out            # 2*N*K*M (src/PrintSpecifications.cpp:40-41)
     assert "Ideal performance:    157286 GOp/s" in out              # 256 CU x 256 FLOP/clk x 2.4 GHz
-    assert "Memory tile size: 128x256" in out and "Frequency:            2400 MHz" in out   # two such workgroups per CU
+    assert "Memory tile size: 256x256" in out and "Frequency:            2400 MHz" in out   # whole rounds of 256 x 256 tiles: that geometry (round 4, by energy)
     comm = int(re.search(r"Communication volume: (\d+)", out).group(1))
-    assert comm == 16384 * 16384 * (1 + 16384 // 128 + 16384 // 256)  # N*M*(1 + K/TN + K/TM), :72-74
+    assert comm == 16384 * 16384 * (1 + 16384 // 256 + 16384 // 256)  # N*M*(1 + K/TN + K/TM), :72-74
+    small = run(exe, 4096, 4096, 4096).stdout                       # one round of tiles: 128 x 256, two such workgroups per CU
+    assert "Memory tile size: 128x256" in small
+    assert int(re.search(r"Communication volume: (\d+)", small).group(1)) == 4096 * 4096 * (1 + 4096 // 128 + 4096 // 256)
     r2 = run(exe, 16384, 16384, 16384, 1200)
     assert "Ideal performance:    78643" in r2.stdout               # scales with the routed frequency
 
@@ -218,8 +221,8 @@ def test_build_time_tile_knob_pins_the_geometry():
     """-DMM_MEMORY_TILE_SIZE_N=256 -DMM_MEMORY_TILE_SIZE_M=256 (reference CMakeLists.txt:18-20 -> Config.h.in:19-23): a
     binary built with the reference's tile knob runs the 256 x 256 geometry where the default build takes the
     library's per-problem pick; no GPU needed to see it (PrintSpecifications reads mm_kernel_info)."""
-    default = run(os.path.join(ROOT, "bin", "PrintSpecifications.exe"), 16384, 16384, 16384).stdout
-    pinned = run(os.path.join(ROOT, "bin", "PrintSpecifications_tile256x256.exe"), 16384, 16384, 16384).stdout
+    default = run(os.path.join(ROOT, "bin", "PrintSpecifications.exe"), 4096, 4096, 4096).stdout
+    pinned = run(os.path.join(ROOT, "bin", "PrintSpecifications_tile256x256.exe"), 4096, 4096, 4096).stdout
     assert "mfma_f32_128x256x16_w4x2_flush4096" in default and "Memory tile size: 128x256" in default
     assert "mfma_f32_256x256x16_w8_flush4096" in pinned and "Memory tile size: 256x256" in pinned
 

@@ -14,9 +14,13 @@ import gemm_hls_amd as g  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--sizes", default="16384,32768")
 ap.add_argument("--reps", type=int, default=5)
+ap.add_argument("--types", default="half,uint8_t")
+ap.add_argument("--min-m", type=int, default=-1, help="kxn_prepass_min_m knob: M from which a K x N A is transposed first (-1 = library default)")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
-for dtype, tdt, knob, pinned in (("half", torch.float16, "f16_variant", 11), ("uint8_t", torch.uint8, "i8_variant", 10)):
+g.set_tuning("kxn_prepass_min_m", args.min_m)
+TYPES = {"half": ("half", torch.float16, "f16_variant", 11), "uint8_t": ("uint8_t", torch.uint8, "i8_variant", 10)}
+for dtype, tdt, knob, pinned in (TYPES[t] for t in args.types.split(",")):
     for s in [int(x) for x in args.sizes.split(",")]:
         a = torch.empty((s, s), dtype=tdt, device=dev)
         b = torch.empty((s, s), dtype=tdt, device=dev)
