@@ -132,7 +132,7 @@ def cpu_baseline(sample_n=1024):
     return info
 
 
-def replayed_counters(kernel_name, shape):
+def replayed_counters(kernel_name, shape, dtype=None):
     """Counters of the kernel this run dispatched, REPLAYED from committed rocprofv3 PMC files (the counter passes
     serialise and slow the kernel, so they are collected separately: tools/pmc_traffic.py = FETCH_SIZE / WRITE_SIZE in
     separate --pmc passes with the guide's gfx950 correction, tools/pmc_mfma.py = SQ / GRBM / TCC passes).  A file is
@@ -151,6 +151,11 @@ def replayed_counters(kernel_name, shape):
         dshape = list(d["shape"]) if "shape" in d else [d.get("size")] * 3
         if dshape != list(shape):
             continue
+        # one kernel NAME can serve several element types (valu_tile is the generic-semiring family): a file that says
+        # which Data_t it profiled only speaks for that one; files from before the field existed profiled float
+        fdtype = d.get("dtype") or ("float" if kernel_name == "valu_tile" else None)
+        if dtype is not None and fdtype is not None and fdtype != dtype:
+            continue
         rel = os.path.relpath(path, ROOT)
         if "hbm_bytes_per_launch" in d and "traffic" not in out:
             out["traffic"] = d["hbm_bytes_per_launch"]
@@ -164,10 +169,10 @@ def replayed_counters(kernel_name, shape):
     return out
 
 
-def attach_replayed(roofline, kernel_name, shape):
+def attach_replayed(roofline, kernel_name, shape, dtype=None):
     """Adds the replayed counters to a roofline object; `achieved_fabric_GBps` = replayed bytes per launch over the
     launch time measured live in this run."""
-    rc = replayed_counters(kernel_name, shape)
+    rc = replayed_counters(kernel_name, shape, dtype)
     if not rc:
         roofline["traffic_note"] = (f"no committed PMC file names kernel {kernel_name!r} at {list(shape)}: traffic and MFMA "
                                     "utilisation not reported rather than replayed from another kernel")
@@ -262,7 +267,7 @@ def extra_workloads(g, torch, dev, local_rank, steps=5):
             if kxn:
                 entry["roofline"]["traffic_note"] = "two kernels per step (transposition pre-pass + product): no single kernel's counters apply"
             else:
-                attach_replayed(entry["roofline"], entry["kernel"], (rows, k, m))
+                attach_replayed(entry["roofline"], entry["kernel"], (rows, k, m), dtype)
             if key in VALU_SUSTAINED:
                 entry["roofline"]["valu_sustained"] = VALU_SUSTAINED[key]
             if key == "float_split":
@@ -419,7 +424,7 @@ def main():
         rl = roofline_obj(dtype, roof, peak, rows, k, m, launch_ms)
         if world == 1:
             attach_replayed(rl, g.kernel_name(g.make_config(dtype, map_op, reduce_op, PATHS.get(args.workload, 0)), rows, k, m),
-                            (rows, k, m))
+                            (rows, k, m), dtype)
         if world == 1:
             what = f"{dtype} {n_total}x{k}x{m} ({map_op},{reduce_op}) on 1 MI355X" + ("; BASELINE configs[1]" if headline else "")
         elif scaling == "strong":

@@ -53,6 +53,21 @@ def test_replayed_counters_only_come_from_files_that_name_the_dispatched_kernel(
     assert abs(rl["achieved_fabric_GBps"] - 51.8e9 / 58.0e-3 / 1e9) < 0.1 and "REPLAYED" in rl["traffic_note"]
 
 
+def test_replayed_counters_of_the_generic_semiring_kernel_are_matched_by_data_type(tmp_path, monkeypatch):
+    """`valu_tile` names the kernel of EVERY Data_t; the double (Add, Min) workload used to replay the
+    float file.  A file that says which type it profiled speaks for that type only; older files (no field) were float."""
+    b = _bench()
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    json.dump({"kernel_name": "valu_tile", "shape": [8192] * 3, "hbm_bytes_per_launch": 5.0e9}, open(prof / "r03_traffic_minplus.json", "w"))
+    json.dump({"kernel_name": "valu_tile", "dtype": "double", "shape": [8192] * 3, "hbm_bytes_per_launch": 13.5e9},
+              open(prof / "r04_traffic_minplus_f64.json", "w"))
+    monkeypatch.setattr(b, "ROOT", str(tmp_path))
+    assert b.replayed_counters("valu_tile", (8192,) * 3, "float")["traffic"] == 5.0e9
+    assert b.replayed_counters("valu_tile", (8192,) * 3, "double")["traffic"] == 13.5e9
+    assert b.replayed_counters("valu_tile", (8192,) * 3, "int") == {}
+
+
 def test_committed_traffic_files_are_self_consistent():
     files = [f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith(".json") and "traffic" in f]
     assert files, "profiles/*traffic*.json missing"

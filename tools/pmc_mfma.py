@@ -79,7 +79,8 @@ def main():
     args = ap.parse_args()
     global VARIANT
     VARIANT = args.variant
-    res = {"kernel": KERNEL[args.what], "kernel_name": dispatched_kernel_name(args.what, args.size, args.variant),
+    dtype_of = {"f32": "float", "f16": "half", "f64": "double", "uint8": "uint8_t", "minplus": "float", "minplus_f64": "double", "split": "float"}
+    res = {"kernel": KERNEL[args.what], "kernel_name": dispatched_kernel_name(args.what, args.size, args.variant), "dtype": dtype_of[args.what],
            "variant": args.variant, "size": args.size, "passes": []}
     flat = {}
     for i, p in enumerate(PASSES):

@@ -82,7 +82,8 @@ def main():
     fetch_kib = sum(fetch) / len(fetch)
     write_kib = sum(write) / len(write)
     res = {
-        "kernel": WHAT[args.what][0], "kernel_name": dispatched_kernel_name(args.what, n, args.variant), "workload": {"f32": "float"}.get(args.what, args.what), "variant": args.variant,
+        "kernel": WHAT[args.what][0], "kernel_name": dispatched_kernel_name(args.what, n, args.variant),
+        "dtype": {"f32": "float", "f16": "half", "f64": "double", "uint8": "uint8_t", "minplus": "float", "minplus_f64": "double", "split": "float"}[args.what], "workload": {"f32": "float"}.get(args.what, args.what), "variant": args.variant,
         "shape": [n, n, n], "launches_profiled": len(fetch),
         "FETCH_SIZE_KiB_raw_per_launch": fetch_kib, "WRITE_SIZE_KiB_raw_per_launch": write_kib,
         "fetch_bytes_corrected": 2.0 * fetch_kib * 1024.0,  # gfx950: 128-B requests tallied as 64 B
