@@ -300,21 +300,31 @@ int mm::streamk_ordered_admit(int dev, hipStream_t s, bool *admitted) {
     (void)hipGetLastError();
     if (s != nullptr) return 0;        // a stream whose mask cannot be read is treated as masked; the null stream has none of its own
   }
-  std::lock_guard<std::mutex> lock(g_streamk_mu);
+  // From here to streamk_ordered_release() the device's stream-K ticket is held: wait-for-previous, launch and
+  // record-behind-it are one step, or two host threads on two streams could both wait for the SAME earlier event and
+  // then run side by side.
+  g_streamk_mu.lock();
   if (!g_streamk_event[dev]) {
-    if ((e = hipEventCreateWithFlags(&g_streamk_event[dev], hipEventDisableTiming)) != hipSuccess) { g_streamk_event[dev] = nullptr; return (int)e; }
+    if ((e = hipEventCreateWithFlags(&g_streamk_event[dev], hipEventDisableTiming)) != hipSuccess) {
+      g_streamk_event[dev] = nullptr;
+      g_streamk_mu.unlock();
+      return (int)e;
+    }
   }
   if (g_streamk_any[dev] && g_streamk_stream[dev] != s) {
-    if ((e = hipStreamWaitEvent(s, g_streamk_event[dev], 0)) != hipSuccess) return (int)e;
+    if ((e = hipStreamWaitEvent(s, g_streamk_event[dev], 0)) != hipSuccess) { g_streamk_mu.unlock(); return (int)e; }
   }
   *admitted = true;
   return 0;
 }
-int mm::streamk_ordered_launched(int dev, hipStream_t s) {
-  std::lock_guard<std::mutex> lock(g_streamk_mu);
-  const hipError_t e = hipEventRecord(g_streamk_event[dev], s);
-  g_streamk_stream[dev] = s;
-  g_streamk_any[dev] = true;
+int mm::streamk_ordered_release(int dev, hipStream_t s, bool launched) {   // after an admitted launch attempt, ALWAYS
+  hipError_t e = hipSuccess;
+  if (launched) {
+    e = hipEventRecord(g_streamk_event[dev], s);
+    g_streamk_stream[dev] = s;
+    g_streamk_any[dev] = true;
+  }
+  g_streamk_mu.unlock();
   return (int)e;
 }
 int mm::device_compute_units(int dev) { return dev >= 0 && dev < 64 && g_device_cus[dev] > 0 ? g_device_cus[dev] : 256; }

@@ -99,9 +99,11 @@ int workspace_release(int device);                       // hands its cached mem
 int flags_alloc(int device, hipStream_t stream, size_t bytes, void **flags, unsigned long long *epoch);
 // Stream-K's in-launch hand-over needs the whole chip and no second launch of its kind next to it (mm_capi.hip):
 // `admitted` = this launch may take that form on (device, stream) -- the stream has then been ordered behind the previous
-// such launch; otherwise the caller runs the two-kernel form.  _launched records the event the next one waits on.
+// such launch and the device's stream-K ticket is HELD until streamk_ordered_release(), which the caller must call on
+// every path after an admission (launched = the kernel went out: record the event the next one waits on); otherwise
+// (not admitted) the caller runs the two-kernel form and releases nothing.
 int streamk_ordered_admit(int device, hipStream_t stream, bool *admitted);
-int streamk_ordered_launched(int device, hipStream_t stream);
+int streamk_ordered_release(int device, hipStream_t stream, bool launched);
 int device_compute_units(int device);                    // as reported by the device when the library initialised
 int mfma_f32_splitk(const Problem &p, int variant);      // K chunks the fp32 MFMA launcher uses for (problem, resolved variant)
 bool mfma_f32_serves(const Problem &p);

@@ -948,20 +948,24 @@ int launch_streamk_ordered(hipStream_t s, const Problem &p) {
   if (int rc = streamk_ordered_admit(dev, s, &admitted)) return rc;
   if (!admitted) return launch_streamk<G>(s, p);
   float *slots = nullptr;
-  const size_t slot_bytes = (size_t)nwg * G::BM * G::BN * sizeof(float);
-  if ((e = hipMallocFromPoolAsync((void **)&slots, slot_bytes, pool, s)) != hipSuccess) return (int)e;
-  if (tuning(TUNE_DEBUG_POISON) == 1 && (e = hipMemsetAsync(slots, 0xFF, slot_bytes, s)) != hipSuccess) { (void)hipFreeAsync(slots, s); return (int)e; }   // NaN everywhere
   void *flags = nullptr;
   unsigned long long epoch = 0;
-  if (int rc = flags_alloc(dev, s, nwg * sizeof(unsigned long long), &flags, &epoch)) { (void)hipFreeAsync(slots, s); return rc; }
-  (void)hipGetLastError();
-  hipLaunchKernelGGL((mfma_f32_streamk_ordered_kernel<G>), dim3(nwg), dim3(G::THREADS), G::LDS_BYTES, s, (const float *)p.a,
-                     (const float *)p.b, (float *)p.c, p.n, p.k, p.m, tiles_n, tiles_m, spt, ts.sr, ts.sc, teams_per_xcd, teams,
-                     slots, (unsigned long long *)flags, epoch);
-  int rc = (int)hipGetLastError();
-  if (rc == 0) rc = streamk_ordered_launched(dev, s);
-  const hipError_t f1 = hipFreeAsync(flags, s), f2 = hipFreeAsync(slots, s);
-  return rc ? rc : f1 != hipSuccess ? (int)f1 : (int)f2;
+  const size_t slot_bytes = (size_t)nwg * G::BM * G::BN * sizeof(float);
+  int rc = (int)hipMallocFromPoolAsync((void **)&slots, slot_bytes, pool, s);
+  if (rc == 0 && tuning(TUNE_DEBUG_POISON) == 1) rc = (int)hipMemsetAsync(slots, 0xFF, slot_bytes, s);   // NaN everywhere
+  if (rc == 0) rc = flags_alloc(dev, s, nwg * sizeof(unsigned long long), &flags, &epoch);
+  bool launched = false;
+  if (rc == 0) {
+    (void)hipGetLastError();
+    hipLaunchKernelGGL((mfma_f32_streamk_ordered_kernel<G>), dim3(nwg), dim3(G::THREADS), G::LDS_BYTES, s, (const float *)p.a,
+                       (const float *)p.b, (float *)p.c, p.n, p.k, p.m, tiles_n, tiles_m, spt, ts.sr, ts.sc, teams_per_xcd, teams,
+                       slots, (unsigned long long *)flags, epoch);
+    rc = (int)hipGetLastError();
+    launched = rc == 0;
+  }
+  const int rel = streamk_ordered_release(dev, s, launched);   // the ticket taken by the admission, on every path
+  const hipError_t f1 = flags ? hipFreeAsync(flags, s) : hipSuccess, f2 = slots ? hipFreeAsync(slots, s) : hipSuccess;
+  return rc ? rc : rel ? rel : f1 != hipSuccess ? (int)f1 : (int)f2;
 }
 
 // C tile = sum of the scratch slots of the workgroups whose ranges cut it, ascending k.  One workgroup per tile; tiles that

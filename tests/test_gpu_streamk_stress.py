@@ -110,6 +110,58 @@ def test_poison_knob_really_poisons_and_the_fixup_form_passes_it_too():
     assert not bool(torch.isnan(plain).any())
 
 
+def test_two_host_threads_on_two_streams_keep_their_bits_and_finish():
+    """Two host threads, each with its own stream, launch stream-K shapes at the same time (poisoned slots).  The library
+    takes a per-device ticket from the admission of a hand-over launch to the event recorded behind it, so the two
+    threads' launches are ordered one behind the other on the GPU instead of sharing it (each holding places the other's
+    producers need); a third thread keeps whole-tile launches running next to them.  Same bits as alone, under a watchdog."""
+    import threading
+    import time
+    import torch
+    dev = torch.device("cuda:0")
+    shapes = [(2341, 2304, 2304), (3584, 512, 3584), (2560, 256, 2560)]
+    ops, alone = [], []
+    for i, (n, k, m) in enumerate(shapes):
+        a = torch.empty((n, k), device=dev).uniform_(-3, 10, generator=torch.Generator(device=dev).manual_seed(40 + i))
+        b = torch.empty((k, m), device=dev).uniform_(-3, 10, generator=torch.Generator(device=dev).manual_seed(50 + i))
+        assert g.kernel_name(g.make_config("float"), n, k, m).endswith("streamk")
+        ops.append((a, b))
+        alone.append(g.matmul(a, b).clone())
+    wa, wb = torch.rand((2048, 2048), device=dev), torch.rand((2048, 2048), device=dev)
+    whole = g.matmul(wa, wb).clone()
+    torch.cuda.synchronize()
+    g.set_tuning("debug_poison", 1)
+    errors, bad, done = [], [], []
+
+    def worker(tid):
+        try:
+            stream = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(stream):
+                for rep in range(150):
+                    if tid == 2:
+                        out = g.matmul(wa, wb)
+                        if not torch.equal(out, whole):
+                            bad.append((tid, rep))
+                        continue
+                    i = (rep + tid) % len(ops)
+                    out = g.matmul(*ops[i])
+                    if not torch.equal(out, alone[i]):       # (the comparison synchronises this thread with its stream)
+                        bad.append((tid, rep, shapes[i], int(torch.isnan(out).sum())))
+            stream.synchronize()
+            done.append(tid)
+        except Exception as exc:
+            errors.append(exc)
+
+    threads = [threading.Thread(target=worker, args=(t,), daemon=True) for t in range(3)]
+    t0 = time.time()
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=max(1.0, 120 - (time.time() - t0)))
+    assert sorted(done) == [0, 1, 2] and not errors, (done, errors)
+    assert not bad, bad[:5]
+
+
 _MASKED_CHILD = r"""
 import ctypes, os, sys
 import torch
