@@ -10,6 +10,7 @@ import ctypes
 import numpy as np
 import pytest
 
+import _bounds
 import _oracle
 import gemm_hls_amd as g
 
@@ -42,7 +43,9 @@ def test_split_vs_blas_and_exact_on_reference_inputs(shape):
     bad, first, worst = _oracle.compare("float", c, a @ b, 1e-5)
     assert bad == 0, (first, worst)
     exact = a.astype(np.float64) @ b.astype(np.float64)
-    assert np.max(np.abs(c - exact) / exact) < 2e-6
+    rel = float(np.max(np.abs(c - exact) / exact))
+    _bounds.north_star(rel, f"MM_PATH_SPLIT {n}x{k}x{m} vs fp64")
+    _bounds.guard(rel, 2e-6, f"MM_PATH_SPLIT {n}x{k}x{m} vs fp64")
 
 
 @pytest.mark.parametrize("k", [16, 32, 48])
@@ -94,7 +97,9 @@ def test_split_flush_chunks_are_deterministic_and_bound_the_drift(variant):
     g.set_tuning("split_variant", 4)
     c1, _ = g.matmul_capi(a, b, path=g.PATH_SPLIT)
     e, e1 = np.max(np.abs(c - exact) / exact), np.max(np.abs(c1 - exact) / exact)
-    assert e < 3e-6 and e <= e1 * 1.25, (e, e1)
+    _bounds.north_star(float(e), "MM_PATH_SPLIT flush chunks vs fp64")
+    _bounds.guard(float(e), 3e-6, "MM_PATH_SPLIT flush chunks vs fp64")
+    assert e <= e1 * 1.25, (e, e1)
 
 
 @pytest.mark.parametrize("shape", [(513, 528, 528), (300, 8300, 272), (257, 17, 255)], ids=lambda s: "x".join(map(str, s)))
@@ -193,7 +198,9 @@ def test_split_non_finite_operands_stay_non_finite():
     keep = np.ones(n, bool)
     keep[[3, 10]] = False
     exact = a[keep].astype(np.float64) @ b.astype(np.float64)
-    assert np.max(np.abs(c[keep] - exact) / exact) < 2e-6
+    rel = float(np.max(np.abs(c[keep] - exact) / exact))
+    _bounds.north_star(rel, "MM_PATH_SPLIT rows without non-finite operands")
+    _bounds.guard(rel, 2e-6, "MM_PATH_SPLIT rows without non-finite operands")
 
 
 def test_split_through_the_multi_device_driver():
