@@ -157,7 +157,10 @@ int mm_gemm_enqueue(void *hip_stream, const mm_config_t *cfg, const void *a_dev,
  * [g*ceil(N/G) ..)), B replicated, no collective.  Host pointers in, host pointer out; copies
  * are outside the timed region exactly as in RunHardware.cpp:140-190.  *elapsed_seconds = from
  * a common start to the last device's completion.  New functionality (the reference is
- * single-device). */
+ * single-device).  With device_count = 1 (or N within one slab) the launch is mm_gemm_launch's.  Row
+ * slabs take every decision that changes a row's summation order (split-K of small fp32 problems) on the whole job, so
+ * a split gives the one-device bits -- except for the mid-size fp32 shapes a single device runs as stream-K (one to two
+ * rounds of 128 x 128 tiles), which slabs run as whole tiles: same contract, different summation order. */
 int mm_gemm_multi_device(int device_count, const mm_config_t *cfg, const void *a_host,
                          const void *b_host, void *c_host, unsigned size_n, unsigned size_k,
                          unsigned size_m, double *elapsed_seconds);
