@@ -481,6 +481,10 @@ int mm_gemm_multi_device(int device_count, const mm_config_t *cfg, const void *a
     return fail(MM_ERR_BAD_ARGUMENT, "device_count %d not in [1, %d]", device_count, g_device_count);
   if (cfg->layout_a == MM_A_TRANSPOSED)
     return fail(MM_ERR_UNSUPPORTED, "row split of a K x N (transposed) A is not contiguous; use one device");
+  if (n == 0 || m == 0) {   // an empty C: nothing to copy, launch or time (the single-device entry points do the same)
+    if (elapsed_seconds) *elapsed_seconds = 0.0;
+    return MM_OK;
+  }
   const size_t es = mm_dtype_size(cfg->dtype);
   // rows per device: ceil(n / G) rounded up to a whole 128-row macro-tile (the same arithmetic as
   // gemm_hls_amd/partition.py), so only the last busy device owns a ragged tile row

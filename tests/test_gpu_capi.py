@@ -197,6 +197,50 @@ def test_host_pointer_entry_with_explicit_config():
     assert np.array_equal(c2, c)
 
 
+def test_empty_and_degenerate_problems_at_every_entry_point():
+    """An empty C (N = 0 or M = 0) is a successful no-op at every entry point -- nothing is launched, C is not touched,
+    null pointers are fine -- and K = 0 is refused (the reference's kernel would leave C unwritten, kernel/Compute.cpp:54-149
+    never runs its k loop; here that is an argument error rather than silently returned garbage).  The device info the
+    library reports is the device's."""
+    import torch
+    L = g.lib()
+    dev = torch.device("cuda:0")
+    cfg = g.make_config("float")
+    a = torch.ones((64, 32), device=dev)
+    b = torch.ones((32, 48), device=dev)
+    c = torch.full((64, 48), 7.0, device=dev)
+    t = ctypes.c_double(-1.0)
+    for (n, m) in ((0, 48), (64, 0), (0, 0)):
+        g._check(L.mm_gemm_launch(0, ctypes.byref(cfg), a.data_ptr(), b.data_ptr(), c.data_ptr(), n, 32, m, ctypes.byref(t)))
+        g._check(L.mm_gemm_enqueue(None, ctypes.byref(cfg), None, None, None, n, 32, m))
+        g._check(L.mm_gemm_host(ctypes.byref(cfg), None, None, None, n, 32, m))
+        t2 = ctypes.c_double(-1.0)
+        g._check(L.mm_gemm_multi_device(1, ctypes.byref(cfg), None, None, None, n, 32, m, ctypes.byref(t2)))
+        assert t2.value == 0.0
+    torch.cuda.synchronize()
+    assert bool((c == 7.0).all())
+    for call in (lambda: L.mm_gemm_launch(0, ctypes.byref(cfg), a.data_ptr(), b.data_ptr(), c.data_ptr(), 64, 0, 48, None),
+                 lambda: L.mm_gemm_enqueue(None, ctypes.byref(cfg), a.data_ptr(), b.data_ptr(), c.data_ptr(), 64, 0, 48),
+                 lambda: L.mm_gemm_host(ctypes.byref(cfg), a.data_ptr(), b.data_ptr(), c.data_ptr(), 64, 0, 48)):
+        assert call() != 0 and b"size_k must be positive" in L.mm_last_error()
+    assert L.mm_gemm_launch(0, ctypes.byref(cfg), None, b.data_ptr(), c.data_ptr(), 64, 32, 48, None) != 0     # a null operand of a non-empty problem
+    assert b"null matrix pointer" in L.mm_last_error()
+    # single-row / single-column-block / single-k-chunk problems: the smallest shapes every fast family serves
+    for dtype, shape in (("float", (1, 8, 4)), ("double", (1, 8, 2)), ("half", (1, 16, 8)), ("uint8_t", (1, 32, 16)), ("int", (1, 4, 4))):
+        n, k, m = shape
+        aa, bb = _oracle.fill(dtype, n, k, m)
+        cc, _ = g.matmul_capi(aa, bb, dtype)
+        want = _oracle.naive(dtype, "Multiply", "Add", aa, bb, wide_half=True) if dtype == "half" else _oracle.naive(dtype, "Multiply", "Add", aa, bb)
+        if dtype in ("float", "double"):
+            assert np.allclose(cc, want, rtol=1e-6), dtype
+        elif dtype == "half":       # exact products, fp32 accumulation, one rounding: within one binary16 ulp of the wide oracle
+            assert np.abs(cc.view(np.int16).astype(np.int32) - want.view(np.int16).astype(np.int32)).max() <= 1
+        else:
+            assert np.array_equal(cc, want), dtype
+    info = g.kernel_info(cfg, 16384, 16384, 16384)
+    assert info.compute_units == torch.cuda.get_device_properties(0).multi_processor_count == 256
+
+
 # ---- multi-GPU ------------------------------------------------------------------------------------
 def test_multi_device_ragged_split_is_bit_identical_to_one_device():
     """Runs wherever >= 2 GPUs are visible (the driver's 8-GPU node; skipped on the 1-GPU box):

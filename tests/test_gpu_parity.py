@@ -604,6 +604,26 @@ def test_f16_i8_wide_kxn_problems_are_transposed_first_and_keep_the_row_major_bi
         assert np.array_equal(c_row[:32], want)
 
 
+@pytest.mark.parametrize("dtype", ["float", "double"])
+def test_non_finite_operands_propagate_like_ieee_and_leave_other_rows_alone(dtype):
+    """inf / NaN in A poison exactly the rows of C they belong to (rows of C are independent, kernel/Compute.cpp:53-60);
+    every other row keeps the bits it has without them.  The reference's Naive gives the same by IEEE arithmetic."""
+    n, k, m = 300, 528, 272
+    a, b = _oracle.fill(dtype, n, k, m)
+    clean, _ = g.matmul_capi(a, b, dtype)
+    a2 = a.copy()
+    a2[7, 3] = np.inf
+    a2[130, 500] = np.nan
+    a2[299, 0] = -np.inf
+    c, _ = g.matmul_capi(a2, b, dtype)
+    assert np.all(np.isposinf(c[7])) and np.all(np.isnan(c[130])) and np.all(np.isneginf(c[299]))
+    keep = np.ones(n, bool)
+    keep[[7, 130, 299]] = False
+    assert np.array_equal(c[keep], clean[keep])
+    want = _oracle.naive(dtype, "Multiply", "Add", a2, b)
+    assert np.array_equal(np.isnan(c), np.isnan(want)) and np.array_equal(np.isinf(c), np.isinf(want))
+
+
 def test_f16_overflow_behaviour_matches_ieee():
     # K large enough that sums pass 65504: binary16 result is +inf, like a correctly rounded result
     n, k, m = 33, 4096, 64
