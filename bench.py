@@ -387,8 +387,14 @@ def main():
         dist.all_reduce(one)                      # every rank of the communicator contributes 1
         ranks_seen = int(one.item())
 
-    from gemm_hls_amd.partition import row_slab
     k = m = args.size
+    job_cfg = g.make_config(dtype, map_op, reduce_op, PATHS.get(args.workload, 0))
+
+    def row_slab(n_total, world_size, r):
+        # the library's own partition (mm_row_slab == what mm_gemm_multi_device does): slabs aligned to the tile
+        # rows of the kernel that will run on them
+        return g.row_slab(job_cfg, n_total, k, m, world_size, r)
+
     headline = args.workload == "float" and args.size == SIZE
 
     def run_job(n_total, seed_base):

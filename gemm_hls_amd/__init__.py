@@ -23,7 +23,8 @@ EXPORTS = ["mm_init", "mm_alloc", "mm_free", "mm_copy_to_device", "mm_copy_to_ho
            "mm_fill_device", "mm_gemm_launch", "mm_gemm_enqueue", "mm_gemm_multi_device",
            "MatrixMultiplicationKernel", "mm_set_default_config", "mm_dtype_size",
            "mm_config_supported", "mm_kernel_name", "mm_kernel_info", "mm_last_error",
-           "mm_gemm_host", "mm_tuning_set", "mm_tuning_get", "mm_release_workspace", "mm_device_pci_bus_id"]
+           "mm_gemm_host", "mm_tuning_set", "mm_tuning_get", "mm_release_workspace", "mm_device_pci_bus_id",
+           "mm_row_slab"]
 
 
 class MMError(RuntimeError):
@@ -89,6 +90,7 @@ def lib():
         L.mm_tuning_get.argtypes = [ctypes.c_char_p, ctypes.POINTER(i)]
         L.mm_release_workspace.argtypes = [i]
         L.mm_device_pci_bus_id.argtypes = [i, ctypes.c_char_p, i]
+        L.mm_row_slab.argtypes = [cfgp, u, u, u, i, i, ctypes.POINTER(u), ctypes.POINTER(u)]
         _lib = L
     return _lib
 
@@ -178,16 +180,23 @@ def matmul(a, b, dtype="float", map_op="Multiply", reduce_op="Add", path=PATH_AU
     return out
 
 
-def matmul_host(a, b, dtype="float", map_op="Multiply", reduce_op="Add", path=PATH_AUTO, devices=1):
+def row_slab(cfg, n, k, m, world_size, rank):
+    """(row0, rows) of `rank`'s slab of the N split, as mm_gemm_multi_device deals the rows out (mm_row_slab)."""
+    row0, rows = ctypes.c_uint(0), ctypes.c_uint(0)
+    _check(lib().mm_row_slab(ctypes.byref(cfg), n, k, m, world_size, rank, ctypes.byref(row0), ctypes.byref(rows)))
+    return row0.value, rows.value
+
+
+def matmul_host(a, b, dtype="float", map_op="Multiply", reduce_op="Add", path=PATH_AUTO, devices=1, transposed_a=False):
     """numpy in, numpy out, through mm_gemm_multi_device (rows of C split over `devices` GPUs).
-    Returns (C, kernel_seconds)."""
+    a: (N, K), or (K, N) with transposed_a.  Returns (C, kernel_seconds)."""
     import numpy as np
     a = np.ascontiguousarray(a)
     b = np.ascontiguousarray(b)
-    n, k = a.shape
-    m = b.shape[1]
+    k, m = b.shape
+    n = a.shape[1] if transposed_a else a.shape[0]
     c = np.empty((n, m), dtype=a.dtype)
-    cfg = make_config(dtype, map_op, reduce_op, path)
+    cfg = make_config(dtype, map_op, reduce_op, path, transposed_a)
     t = ctypes.c_double(0)
     _check(lib().mm_gemm_multi_device(devices, ctypes.byref(cfg), a.ctypes.data, b.ctypes.data, c.ctypes.data,
                                       n, k, m, ctypes.byref(t)))

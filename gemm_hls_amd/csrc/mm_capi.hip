@@ -91,9 +91,11 @@ mm_config_t default_cfg() {
 std::once_flag g_tuning_once;
 std::atomic<int> g_tuning[mm::TUNE_COUNT];
 const char *const kTuneName[mm::TUNE_COUNT] = {"f32_variant", "f64_variant", "f16_variant", "i8_variant", "band_rows",
-                                               "valu_variant", "split_variant", "f32_splitk", "ablations", "debug_poison", "kxn_prepass_min_m"};
+                                               "valu_variant", "split_variant", "f32_splitk", "ablations", "debug_poison", "kxn_prepass_min_m",
+                                               "md_virtual_devices"};
 const char *const kTuneEnv[mm::TUNE_COUNT] = {"MM_F32_VARIANT", "MM_F64_VARIANT", "MM_F16_VARIANT", "MM_I8_VARIANT",
-                                              "MM_BAND_ROWS", "MM_VALU_VARIANT", "MM_SPLIT_VARIANT", "MM_F32_SPLITK", "MM_ABLATIONS", "MM_DEBUG_POISON", "MM_KXN_PREPASS_MIN_M"};
+                                              "MM_BAND_ROWS", "MM_VALU_VARIANT", "MM_SPLIT_VARIANT", "MM_F32_SPLITK", "MM_ABLATIONS", "MM_DEBUG_POISON", "MM_KXN_PREPASS_MIN_M",
+                                              "MM_MD_VIRTUAL_DEVICES"};
 void tuning_init() {
   for (int i = 0; i < mm::TUNE_COUNT; ++i) {
     const char *e = getenv(kTuneEnv[i]);
@@ -126,7 +128,13 @@ int f32_variant_for(const mm::Problem &p) { return mm::mfma_f32_resolve(p, f32_v
 enum Family { FAM_ORDERED, FAM_VALU_TILE, FAM_MFMA_F32, FAM_MFMA_F64, FAM_MFMA_F16, FAM_MFMA_I8, FAM_HALF_WIDE,
               FAM_F32_SPLIT, FAM_NONE };
 
-Family choose(const mm_config_t &cfg, const mm::Problem &p) {
+// The family is a property of the JOB: a row slab of a bigger job (Problem::n_total) runs the family the whole job would
+// run, so that a split never changes which arithmetic a row gets.  (Row-major slabs qualify for whatever the job
+// qualifies for -- the families only ask n >= 1; a K x N A asks for N % 4 / 2 / 8 / 16 == 0, which tile-aligned slabs of
+// an N that has it keep, the last one included.)
+Family choose(const mm_config_t &cfg, const mm::Problem &slab) {
+  mm::Problem p = slab;
+  if (slab.n_total) { p.n = slab.n_total; p.n_total = 0; }
   if (cfg.path == MM_PATH_ORDERED) return FAM_ORDERED;
   const bool mul_add = cfg.map_op == MM_OP_MULTIPLY && cfg.reduce_op == MM_OP_ADD;
   if (cfg.path == MM_PATH_SPLIT)  // an explicit request is never re-routed: fp32 (x,+) or nothing
@@ -346,6 +354,8 @@ int mm::tuning(mm::Tunable t) {
   return g_tuning[t].load(std::memory_order_relaxed);
 }
 
+static void kernel_info_for(const mm_config_t *cfg, const mm::Problem &p, mm_kernel_info_t *info);
+
 extern "C" {
 
 const char *mm_last_error(void) { return g_error; }
@@ -471,118 +481,156 @@ int mm_gemm_launch(int device, const mm_config_t *cfg, const void *a, const void
   return MM_OK;
 }
 
+// Rows per device of the N split: ceil(N / G) rounded up to whole tile rows of the kernel that will run on a slab of that
+// height (mm_kernel_info's tile_n: 256 for the large fp32 default, 128 / 64 for the smaller geometries), so that only the last busy
+// device owns a ragged tile row.  The one place this arithmetic lives: mm_row_slab() hands it to bench.py and partition.py.
+static unsigned md_slab_rows(const mm_config_t &cfg, unsigned n, unsigned k, unsigned m, int device_count) {
+  if (n == 0) return 0;
+  const size_t base = ((size_t)n + device_count - 1) / device_count;
+  const unsigned cand = (unsigned)std::min<size_t>(n, (base + 127) / 128 * 128);
+  mm_kernel_info_t info = {};
+  const mm::Problem p{nullptr, nullptr, nullptr, cand, k, m, cfg.layout_a == MM_A_TRANSPOSED, cand == n ? 0u : n};
+  kernel_info_for(&cfg, p, &info);
+  const size_t tile = info.tile_n ? info.tile_n : 128;
+  return (unsigned)std::min<size_t>(n, (base + tile - 1) / tile * tile);
+}
+
+int mm_row_slab(const mm_config_t *cfg, unsigned n, unsigned k, unsigned m, int device_count, int rank, unsigned *row0,
+                unsigned *rows) {
+  if (!valid_cfg(cfg) || !row0 || !rows) return fail(MM_ERR_BAD_ARGUMENT, "invalid arguments to mm_row_slab");
+  if (device_count < 1 || rank < 0 || rank >= device_count)
+    return fail(MM_ERR_BAD_ARGUMENT, "rank %d not in [0, device_count = %d)", rank, device_count);
+  const unsigned slab = md_slab_rows(*cfg, n, k ? k : 1, m, device_count);
+  *row0 = (unsigned)std::min<size_t>((size_t)rank * slab, n);
+  *rows = std::min(slab, n - *row0);
+  return MM_OK;
+}
+
+namespace {
+// What one logical device of the N split owns; everything is released by the destructor, on every path.
+struct SplitDevice {
+  int phys = 0;                       // the HIP device this logical device runs on
+  void *a = nullptr, *b = nullptr, *c = nullptr;
+  unsigned row0 = 0, rows = 0;
+  hipStream_t s = nullptr;
+  ~SplitDevice() {
+    if (!a && !b && !c && !s) return;
+    (void)hipSetDevice(phys);
+    if (s) (void)hipStreamSynchronize(s);
+    if (a) (void)hipFree(a);
+    if (b) (void)hipFree(b);
+    if (c) (void)hipFree(c);
+    if (s) (void)hipStreamDestroy(s);
+  }
+};
+}  // namespace
+
 int mm_gemm_multi_device(int device_count, const mm_config_t *cfg, const void *a_host, const void *b_host,
                          void *c_host, unsigned n, unsigned k, unsigned m, double *elapsed_seconds) {
   int rc = ensure_init();
   if (rc) return rc;
   rc = check_problem(cfg, a_host, b_host, c_host, n, k, m);
   if (rc) return rc;
-  if (device_count < 1 || device_count > g_device_count)
-    return fail(MM_ERR_BAD_ARGUMENT, "device_count %d not in [1, %d]", device_count, g_device_count);
-  if (cfg->layout_a == MM_A_TRANSPOSED)
-    return fail(MM_ERR_UNSUPPORTED, "row split of a K x N (transposed) A is not contiguous; use one device");
+  // MM_MD_VIRTUAL_DEVICES / "md_virtual_devices" = V > 0 (tests): up to V LOGICAL devices, dealt out over the physical ones
+  // round-robin -- on a 1-GPU box all of them on device 0, each with its own stream, slabs and copy of B, the B fan-out
+  // taking the peer-copy branch (device 0 -> device 0).  Every line below is the one a real G-GPU node runs.
+  const int virt = mm::tuning(mm::TUNE_MD_VIRTUAL_DEVICES);
+  const int limit = virt > 0 ? virt : g_device_count;
+  if (device_count < 1 || device_count > limit)
+    return fail(MM_ERR_BAD_ARGUMENT, "device_count %d not in [1, %d]", device_count, limit);
   if (n == 0 || m == 0) {   // an empty C: nothing to copy, launch or time (the single-device entry points do the same)
     if (elapsed_seconds) *elapsed_seconds = 0.0;
     return MM_OK;
   }
   const size_t es = mm_dtype_size(cfg->dtype);
-  // rows per device: ceil(n / G) rounded up to a whole 128-row macro-tile (the same arithmetic as
-  // gemm_hls_amd/partition.py), so only the last busy device owns a ragged tile row
-  const unsigned slab = (unsigned)std::min<size_t>(n, (((size_t)n + device_count - 1) / device_count + 127) / 128 * 128);
-  struct Dev { void *a = nullptr, *b = nullptr, *c = nullptr; unsigned row0 = 0, rows = 0; hipStream_t s = nullptr; };
-  std::vector<Dev> devs(device_count);
-  auto cleanup = [&]() {
-    for (int g = 0; g < device_count; ++g) {
-      (void)hipSetDevice(g);
-      if (devs[g].a) (void)hipFree(devs[g].a);
-      if (devs[g].b) (void)hipFree(devs[g].b);
-      if (devs[g].c) (void)hipFree(devs[g].c);
-      if (devs[g].s) (void)hipStreamDestroy(devs[g].s);
-    }
-  };
-#define MM_HIP_MD(call)                                                  \
-  do {                                                                   \
-    hipError_t e_ = (call);                                              \
-    if (e_ != hipSuccess) { cleanup(); return hip_fail(e_, #call); }     \
+  const bool kxn = cfg->layout_a == MM_A_TRANSPOSED;
+  const unsigned slab = md_slab_rows(*cfg, n, k, m, device_count);
+  std::vector<SplitDevice> devs(device_count);
+#define MM_HIP_MD(call)                                       \
+  do {                                                        \
+    hipError_t e_ = (call);                                   \
+    if (e_ != hipSuccess) return hip_fail(e_, #call);         \
   } while (0)
-  // independent row slabs: device g owns C[row0 : row0+rows, :] = A[row0 : row0+rows, :] . B
+  // independent row slabs: logical device g owns C[row0 : row0+rows, :] = A[row0 : row0+rows, :] . B
+  // (kernel/Compute.cpp:53-60: no outer tile of C depends on another one)
   for (int g = 0; g < device_count; ++g) {
-    Dev &d = devs[g];
+    SplitDevice &d = devs[g];
+    d.phys = g % g_device_count;
     d.row0 = (unsigned)std::min<size_t>((size_t)g * slab, n);
     d.rows = std::min(slab, n - d.row0);
-    MM_HIP_MD(hipSetDevice(g));
+    MM_HIP_MD(hipSetDevice(d.phys));
     MM_HIP_MD(hipStreamCreateWithFlags(&d.s, hipStreamNonBlocking));
+    if (!d.rows) continue;          // a trailing device without rows takes no part (and no copy of B)
     MM_HIP_MD(hipMalloc(&d.b, (size_t)k * m * es));
-    if (d.rows) {
-      MM_HIP_MD(hipMalloc(&d.a, (size_t)d.rows * k * es));
-      MM_HIP_MD(hipMalloc(&d.c, (size_t)d.rows * m * es));
-    }
+    MM_HIP_MD(hipMalloc(&d.a, (size_t)d.rows * k * es));
+    MM_HIP_MD(hipMalloc(&d.c, (size_t)d.rows * m * es));
   }
   // B crosses PCIe ONCE (host -> device 0) and is then fanned out device 0 -> device g over xGMI
   // (every GPU has its own link to GPU 0, so the G-1 peer copies run concurrently), instead of G
   // pageable host copies through one root complex; the A slabs go up meanwhile.  A device that
   // cannot take the peer copy gets B from the host as before.
   Event b_on_dev0;
-  MM_HIP_MD(hipSetDevice(0));
+  MM_HIP_MD(hipSetDevice(devs[0].phys));
   MM_HIP_MD(hipEventCreateWithFlags(&b_on_dev0.e, hipEventDisableTiming));
   MM_HIP_MD(hipMemcpyAsync(devs[0].b, b_host, (size_t)k * m * es, hipMemcpyHostToDevice, devs[0].s));
   MM_HIP_MD(hipEventRecord(b_on_dev0.e, devs[0].s));
   for (int g = 0; g < device_count; ++g) {
-    Dev &d = devs[g];
-    MM_HIP_MD(hipSetDevice(g));
+    SplitDevice &d = devs[g];
+    if (!d.rows) continue;
+    MM_HIP_MD(hipSetDevice(d.phys));
     if (g > 0) {
-      int can = 0;
-      bool peer = hipDeviceCanAccessPeer(&can, g, 0) == hipSuccess && can;
-      if (peer) {
-        const hipError_t en = hipDeviceEnablePeerAccess(0, 0);
-        peer = en == hipSuccess || en == hipErrorPeerAccessAlreadyEnabled;
-        (void)hipGetLastError();  // "already enabled" is not an error of this call
+      bool peer = d.phys == devs[0].phys;          // the same physical device (virtual devices): a peer copy onto itself
+      if (!peer) {
+        int can = 0;
+        peer = hipDeviceCanAccessPeer(&can, d.phys, devs[0].phys) == hipSuccess && can;
+        if (peer) {
+          const hipError_t en = hipDeviceEnablePeerAccess(devs[0].phys, 0);
+          peer = en == hipSuccess || en == hipErrorPeerAccessAlreadyEnabled;
+        }
+        (void)hipGetLastError();  // "already enabled" / "no peer" are not errors of this call
       }
       if (peer) {
         MM_HIP_MD(hipStreamWaitEvent(d.s, b_on_dev0.e, 0));
-        MM_HIP_MD(hipMemcpyPeerAsync(d.b, g, devs[0].b, 0, (size_t)k * m * es, d.s));
+        MM_HIP_MD(hipMemcpyPeerAsync(d.b, d.phys, devs[0].b, devs[0].phys, (size_t)k * m * es, d.s));
       } else {
         MM_HIP_MD(hipMemcpyAsync(d.b, b_host, (size_t)k * m * es, hipMemcpyHostToDevice, d.s));
       }
     }
-    if (d.rows)
+    if (!kxn) {   // rows [row0, row0 + rows) of a row-major A: one contiguous block
       MM_HIP_MD(hipMemcpyAsync(d.a, (const char *)a_host + (size_t)d.row0 * k * es, (size_t)d.rows * k * es,
                                hipMemcpyHostToDevice, d.s));
+    } else {      // the same rows of a K x N A (MM_TRANSPOSED_A, kernel/Memory.cpp:205-261): COLUMNS [row0, row0 + rows) of every
+                  // one of its K rows -> a dense K x rows matrix on the device
+      MM_HIP_MD(hipMemcpy2DAsync(d.a, (size_t)d.rows * es, (const char *)a_host + (size_t)d.row0 * es, (size_t)n * es,
+                                 (size_t)d.rows * es, k, hipMemcpyHostToDevice, d.s));
+    }
   }
-  for (int g = 0; g < device_count; ++g) { MM_HIP_MD(hipSetDevice(g)); MM_HIP_MD(hipStreamSynchronize(devs[g].s)); }
+  for (SplitDevice &d : devs) { MM_HIP_MD(hipSetDevice(d.phys)); MM_HIP_MD(hipStreamSynchronize(d.s)); }
   // untimed warm-up pass of the same launch: the first dispatch on a device loads the code object,
   // opts the kernel into its LDS size and ramps the clocks; paying that outside the timed region
-  // makes this figure comparable with mm_gemm_launch's (whose callers warm up the same way)
-  for (int g = 0; g < device_count; ++g) {
-    Dev &d = devs[g];
-    if (!d.rows) continue;
-    MM_HIP_MD(hipSetDevice(g));
-    mm::Problem warm{d.a, d.b, d.c, d.rows, k, m, false, d.rows == n ? 0u : n};
-    rc = dispatch(d.s, *cfg, warm);
-    if (rc) { cleanup(); return rc; }
+  // makes this figure comparable with mm_gemm_launch's (whose callers warm up the same way).
+  // pass 1 is the timed region: common start -> every device complete (copies excluded, as RunHardware.cpp does)
+  double elapsed = 0.0;
+  for (int pass = 0; pass < 2; ++pass) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (SplitDevice &d : devs) {
+      if (!d.rows) continue;
+      MM_HIP_MD(hipSetDevice(d.phys));
+      // a row slab of the n-row job (n_total 0: the slab IS the job -- the same launch as mm_gemm_launch's)
+      const mm::Problem p{d.a, d.b, d.c, d.rows, k, m, kxn, d.rows == n ? 0u : n};
+      rc = dispatch(d.s, *cfg, p);
+      if (rc) return rc;
+    }
+    for (SplitDevice &d : devs) { MM_HIP_MD(hipSetDevice(d.phys)); MM_HIP_MD(hipStreamSynchronize(d.s)); }
+    elapsed = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   }
-  for (int g = 0; g < device_count; ++g) { MM_HIP_MD(hipSetDevice(g)); MM_HIP_MD(hipStreamSynchronize(devs[g].s)); }
-  // timed region: common start -> every device complete (copies excluded, as RunHardware.cpp does)
-  const auto t0 = std::chrono::steady_clock::now();
-  for (int g = 0; g < device_count; ++g) {
-    Dev &d = devs[g];
+  if (elapsed_seconds) *elapsed_seconds = elapsed;
+  for (SplitDevice &d : devs) {
     if (!d.rows) continue;
-    MM_HIP_MD(hipSetDevice(g));
-    mm::Problem p{d.a, d.b, d.c, d.rows, k, m, false, d.rows == n ? 0u : n};   // a row slab of the n-row job (0: the slab IS the job -- the same launch as mm_gemm_launch's)
-    rc = dispatch(d.s, *cfg, p);
-    if (rc) { cleanup(); return rc; }
-  }
-  for (int g = 0; g < device_count; ++g) { MM_HIP_MD(hipSetDevice(g)); MM_HIP_MD(hipStreamSynchronize(devs[g].s)); }
-  const auto t1 = std::chrono::steady_clock::now();
-  if (elapsed_seconds) *elapsed_seconds = std::chrono::duration<double>(t1 - t0).count();
-  for (int g = 0; g < device_count; ++g) {
-    Dev &d = devs[g];
-    if (!d.rows) continue;
-    MM_HIP_MD(hipSetDevice(g));
+    MM_HIP_MD(hipSetDevice(d.phys));
     MM_HIP_MD(hipMemcpy((char *)c_host + (size_t)d.row0 * m * es, d.c, (size_t)d.rows * m * es, hipMemcpyDeviceToHost));
   }
 #undef MM_HIP_MD
-  cleanup();
   return MM_OK;
 }
 
@@ -724,8 +772,18 @@ const char *mm_kernel_name(const mm_config_t *cfg, unsigned n, unsigned k, unsig
 int mm_kernel_info(const mm_config_t *cfg, unsigned n, unsigned k, unsigned m, mm_kernel_info_t *info) {
   if (!valid_cfg(cfg) || !info) return fail(MM_ERR_BAD_ARGUMENT, "invalid arguments to mm_kernel_info");
   mm::Problem p{nullptr, nullptr, nullptr, n, k, m, cfg->layout_a == MM_A_TRANSPOSED};
+  kernel_info_for(cfg, p, info);
+  return MM_OK;
+}
+
+}  // extern "C"
+
+static void kernel_info_for(const mm_config_t *cfg, const mm::Problem &p, mm_kernel_info_t *info) {
   mm_kernel_info_t r = {};
-  r.compute_units = (unsigned)mm::device_compute_units(0);   // what device 0 reports once the library is initialised; the MI355X's 256 before
+  // the CURRENT device's compute units once the library is initialised (not device 0's); the MI355X's 256 before
+  int cur = 0;
+  if (g_init_status != MM_OK || hipGetDevice(&cur) != hipSuccess) { (void)hipGetLastError(); cur = 0; }
+  r.compute_units = (unsigned)mm::device_compute_units(cur);
   r.max_clock_mhz = 2400.0;
   switch (choose(*cfg, p)) {
     case FAM_MFMA_F32:
@@ -793,7 +851,4 @@ int mm_kernel_info(const mm_config_t *cfg, unsigned n, unsigned k, unsigned m, m
       break;
   }
   *info = r;
-  return MM_OK;
 }
-
-}  // extern "C"

@@ -159,6 +159,8 @@ enum Tunable {
   TUNE_DEBUG_POISON,     // MM_DEBUG_POISON 1 = fill scratch the kernels hand data through (stream-K slots) with NaN before
                          //                 every launch: a read of anything this launch did not write shows up in C
   TUNE_KXN_PREPASS_MIN_M,  // MM_KXN_PREPASS_MIN_M  half / int8 with a K x N A: M from which the transposition pre-pass is taken (-1: 6144)
+  TUNE_MD_VIRTUAL_DEVICES, // MM_MD_VIRTUAL_DEVICES  G > 0: mm_gemm_multi_device accepts device_count <= G and deals its logical devices
+                           //                 out over the physical ones round-robin (tests: every g > 0 branch on a 1-GPU box)
   TUNE_COUNT
 };
 int tuning(Tunable t);  // mm_capi.hip

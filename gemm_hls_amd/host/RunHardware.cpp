@@ -151,7 +151,12 @@ int main(int argc, char **argv) {
     std::cout << "Initializing HIP context...\n" << std::flush;
     int device_count = 0;
     Check(mm_init(&device_count), "mm_init");
-    if (gpus > device_count) throw std::runtime_error("MM_GPUS exceeds the number of visible devices");
+    {  // MM_GPUS beyond the visible devices is an error -- unless the library was told to deal logical devices out over
+       // the physical ones (MM_MD_VIRTUAL_DEVICES, tests on a 1-GPU box), which mm_gemm_multi_device then bounds itself
+      int virt = -1;
+      (void)mm_tuning_get("md_virtual_devices", &virt);
+      if (gpus > std::max(device_count, virt)) throw std::runtime_error("MM_GPUS exceeds the number of visible devices");
+    }
 
     double elapsed = 0.0;
 #ifdef MM_POWER_METER

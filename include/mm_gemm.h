@@ -153,17 +153,27 @@ int mm_gemm_enqueue(void *hip_stream, const mm_config_t *cfg, const void *a_dev,
                     const void *b_dev, void *c_dev, unsigned size_n, unsigned size_k,
                     unsigned size_m);
 
-/* One node, `device_count` GPUs, rows of C split into contiguous slabs (device g gets rows
- * [g*ceil(N/G) ..)), B replicated, no collective.  Host pointers in, host pointer out; copies
- * are outside the timed region exactly as in RunHardware.cpp:140-190.  *elapsed_seconds = from
- * a common start to the last device's completion.  New functionality (the reference is
- * single-device).  With device_count = 1 (or N within one slab) the launch is mm_gemm_launch's.  Row
- * slabs take every decision that changes a row's summation order (split-K of small fp32 problems) on the whole job, so
- * a split gives the one-device bits -- except for the mid-size fp32 shapes a single device runs as stream-K (one to two
- * rounds of 128 x 128 tiles), which slabs run as whole tiles: same contract, different summation order. */
+/* One node, `device_count` GPUs, rows of C split into contiguous slabs (device g gets the rows mm_row_slab() names), B
+ * replicated, no collective: every outer tile of C is independent (kernel/Compute.cpp:53-60, kernel/Memory.cpp:114-127,
+ * 272-286, 367-391).  Host pointers in, host pointer out; copies are outside the timed region exactly as in
+ * RunHardware.cpp:140-190.  *elapsed_seconds = from a common start to the last device's completion.  New functionality
+ * (the reference is single-device).  A K x N A (MM_A_TRANSPOSED == MM_TRANSPOSED_A, kernel/Memory.cpp:205-261)
+ * is split along its columns (one strided copy per device).  With device_count = 1 (or N within one slab) the launch is
+ * mm_gemm_launch's.  The kernel FAMILY and every decision that changes a row's summation order (split-K of small fp32
+ * problems) are taken on the whole job, so a split gives the one-device bits -- except for the mid-size fp32 shapes a
+ * single device runs as stream-K (one to two rounds of 128 x 128 tiles), which slabs run as whole tiles: same contract,
+ * different summation order.
+ * Tests only: "md_virtual_devices" = V (MM_MD_VIRTUAL_DEVICES) lets device_count go up to V LOGICAL devices dealt out over
+ * the physical ones round-robin, so that every per-device branch runs on a 1-GPU box. */
 int mm_gemm_multi_device(int device_count, const mm_config_t *cfg, const void *a_host,
                          const void *b_host, void *c_host, unsigned size_n, unsigned size_k,
                          unsigned size_m, double *elapsed_seconds);
+/* The row partition mm_gemm_multi_device uses, for callers that drive one process per GPU themselves (bench.py):
+ * slabs of ceil(N / G) rows rounded up to whole tile rows of the kernel that will run on them (mm_kernel_info's tile_n),
+ * so only the last busy device owns a ragged tile row; trailing devices may get *rows = 0.  Pure arithmetic: works
+ * without a device. */
+int mm_row_slab(const mm_config_t *cfg, unsigned size_n, unsigned size_k, unsigned size_m, int device_count, int rank,
+                unsigned *row0, unsigned *rows);
 
 /* extern "C" void MatrixMultiplicationKernel(MemoryPackK_t const a[], MemoryPackM_t const b[],
  * MemoryPackM_t c[], unsigned size_n, unsigned size_k, unsigned size_m)

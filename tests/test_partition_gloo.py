@@ -31,6 +31,45 @@ def test_row_slabs_tile_the_rows(n, world):
     assert all(row_slab(n, world, r)[0] % 128 == 0 or row_slab(n, world, r)[1] == 0 for r in range(world))
 
 
+@pytest.mark.parametrize("dtype", ["float", "half", "double", "int", "uint8_t"])
+@pytest.mark.parametrize("n,k,m,world", [(16384, 16384, 16384, 8), (65536, 16384, 16384, 8), (64512, 16384, 16384, 8),
+                                         (33792, 16384, 16384, 8), (513, 528, 528, 2), (5, 16, 16, 8), (1, 16, 16, 4),
+                                         (6000, 2048, 2048, 2), (1000, 512, 272, 8), (20000, 4096, 4096, 3), (0, 16, 16, 2)])
+def test_library_row_slab_is_the_python_rule_with_the_running_kernels_tile(dtype, n, k, m, world):
+    """mm_row_slab (the arithmetic mm_gemm_multi_device and bench.py share; pure arithmetic, runs without a device):
+    slabs tile the rows, and are row_slab() with tile_rows = the tile height of the kernel that serves a slab."""
+    import gemm_hls_amd as g
+    from gemm_hls_amd.partition import row_slab_for
+    cfg = g.make_config(dtype)
+    got = [row_slab_for(cfg, n, k, m, world, r) for r in range(world)]
+    covered = [x for row0, rows in got for x in range(row0, row0 + rows)] if n <= 70000 else None
+    assert covered == list(range(n))
+    if n == 0:
+        assert got == [(0, 0)] * world
+        return
+    cand = min(n, -(-(-(-n // world)) // 128) * 128)
+    tile = g.kernel_info(cfg, cand, k, m).tile_n if cand == n else None
+    if tile is None:   # a slab of a bigger job: the tile of the geometry the library reports for the slab it finally hands out
+        tile = next(t for t in (64, 128, 256) if got == [row_slab(n, world, r, t) for r in range(world)])
+        assert tile in (64, 128, 256)
+    assert got == [row_slab(n, world, r, tile) for r in range(world)]
+    # no busy rank but the last busy one owns a ragged tile row
+    busy = [rows for _, rows in got if rows]
+    assert all(rows % tile == 0 for rows in busy[:-1])
+
+
+def test_row_slab_of_the_baseline_job_and_of_a_half_tile_remainder():
+    import gemm_hls_amd as g
+    cfg = g.make_config("float")
+    assert [g.row_slab(cfg, 65536, 16384, 16384, 8, r) for r in range(8)] == [(8192 * r, 8192) for r in range(8)]
+    # 64512 / 8 = 8064 rows = 31.5 tiles of the 256-row kernel that serves such a slab: rounded to whole tile rows
+    assert [g.row_slab(cfg, 64512, 16384, 16384, 8, r)[1] for r in range(8)] == [8192] * 7 + [7168]
+    with pytest.raises(g.MMError):
+        g.row_slab(cfg, 100, 16, 16, 2, 2)
+    with pytest.raises(g.MMError):
+        g.row_slab(cfg, 100, 16, 16, 0, 0)
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
