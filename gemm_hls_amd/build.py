@@ -166,6 +166,10 @@ def build(verbose=True):
     shim(f"libmmkernel_static_float_{tag}.so", defs(dt, mp, rd, static))
     shim("libmmkernel_transposedA.so", defs(dt, mp, rd, transposed=True))
     shim("libmmkernel_half.so", defs("half", mp, rd))
+    # the same library over the k-ordered kernel (MM_PATH_ORDERED): the bit-true "simulation" build.  The reference's own
+    # test/TestSimulation.cpp compares half results EXACTLY with its binary16-accumulating Naive (its `half` is not
+    # std::is_floating_point, test/TestSimulation.cpp:80-85) -- tests/ref_hosts links it against this one
+    shim("libmmkernel_half_ordered.so", defs("half", mp, rd) + ["-DMM_DEFAULT_PATH=MM_PATH_ORDERED"])
     exe("TestSimulation.exe", "TestSimulation.cpp", defs(dt, mp, rd), shim="libmmkernel.so")
     exe(f"TestSimulation_static_float_{tag}.exe", "TestSimulation.cpp", defs(dt, mp, rd, static),
         shim=f"libmmkernel_static_float_{tag}.so")

@@ -58,7 +58,7 @@ _TIERS = [
     (1, ("test_minplus_8192_", "test_double_16384_", "test_half_32768_", "test_uint8_32768_", "test_f32_full_size_properties",
          "test_f32_baseline_c5a_shape_", "test_f32_mixed_sign_full_size_sampled", "test_split_full_size_sampled_rows",
          "test_split_c5a_shape_")),
-    (2, ("tests/test_run_hardware_cli.py", "tests/test_gpu_benchmark_driver.py")),
+    (2, ("tests/test_gpu_ref_hosts.py", "tests/test_run_hardware_cli.py", "tests/test_gpu_benchmark_driver.py")),
     (3, ("test_multi_device_", "tests/test_gpu_capi.py")),
     # tier 5 (default): the rest of the parity matrix
     # tier 7: shape-dispatch stress, hand-over stress, fuzz, soak
