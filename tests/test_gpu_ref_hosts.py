@@ -115,8 +115,11 @@ def test_reference_hosts_half_build_is_exact():
     r = _run("half", "TestSimulation.exe", 513, 544, 544)
     assert r.returncode == 0 and "successfully verified" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
     r = _run("half", "RunHardware.exe", 8192, 8192, 8192, "hw", "off")
-    assert r.returncode == 0 and PERF.search(r.stdout), r.stdout[-2000:] + r.stderr[-2000:]
-    assert float(PERF.search(r.stdout).group(2)) > 500e3       # matrix cores, not the ordered kernel
+    # (above 1e6 GOp/s the reference's `std::cout << perf` prints 1.3e+06, which its own parser's [\d\.]+ cannot read:
+    # a limit of the reference's print statement, left as it is -- this repository's runner prints fixed notation there)
+    mo = re.search(r"performance of ([\d\.e\+]+) GOp/s", r.stdout)
+    assert r.returncode == 0 and mo, r.stdout[-2000:] + r.stderr[-2000:]
+    assert float(mo.group(1)) > 500e3       # matrix cores, not the ordered kernel
 
 
 @pytest.mark.gpu
