@@ -69,8 +69,8 @@ def build_lab(product_objs, headers, verbose=True):
     """tools/lab/libmm_gemm_amd_lab.so: the SAME C ABI with the four matrix-core translation units swapped for their
     lab editions (every schedule / ring depth / ablation the kernels went through, incl. the ones that skip work on
     purpose).  Measurement tooling only (MM_LIB=lab for tools/sweep.py and friends); nothing in the product links it."""
-    if not os.path.isdir(LAB_DIR):
-        return
+    if not os.path.isdir(LAB_DIR) or os.environ.get("MM_BUILD_LAB") != "1":
+        return   # measurement tooling: built on request only (MM_BUILD_LAB=1), not by every build()
     os.makedirs(os.path.join(LAB_DIR, "_obj"), exist_ok=True)
     jobs, lab_objs = [], []
     for src, replaced in LAB_REPLACES.items():

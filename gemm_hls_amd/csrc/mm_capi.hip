@@ -276,65 +276,73 @@ int mm::flags_alloc(int dev, hipStream_t s, size_t bytes, void **out, unsigned l
   return 0;
 }
 
-// Stream-K with the hand-over inside the launch (mm_mfma_f32.hip: mfma_f32_streamk_ordered_kernel) has workgroups wait
-// on flags that other workgroups of the SAME launch raise.  That is only sound when every workgroup of the launch gets a
-// place on the chip without one of the waiting ones having to leave first:
+// Stream-K with the hand-over inside the launch (mm_mfma_f32.hip: mfma_f32_streamk_ordered_kernel<G, true>; opt-in through
+// f32_splitk = 10, never taken by MM_PATH_AUTO) has workgroups wait on flags that other workgroups of the SAME launch raise.
+// That is only sound when every workgroup of the launch gets a place on the chip without one of the waiting ones having to
+// leave first:
 //   * the device has the 256 CUs (8 XCDs x 32) the launch's 512 places are counted on, and the stream is not CU-masked;
 //   * no second launch of that kind competes for the places: two of them, each holding part of the chip with workgroups
 //     that wait for workgroups the other one keeps from being dispatched, would wait for ever.  So such
 //     launches are serialised per device: each one's stream first waits for the event recorded behind the previous one
-//     (ordinary kernels next to it are fine -- they finish and hand their places over);
+//     (ordinary kernels next to it are fine -- they finish and hand their places over).  This orders the launches of THIS
+//     PROCESS only; whoever opts in vouches that no other process runs such launches on the device;
 //   * the stream is not being captured: replays of a graph are launched by the application, outside this ordering.
-// Where any of this does not hold, the launcher runs the two-kernel form (slots for every part, a fix-up kernel adds
-// them in ascending k: no waiting inside a kernel), equally deterministic.
-static hipEvent_t g_streamk_event[64] = {};
-static hipStream_t g_streamk_stream[64] = {};
-static bool g_streamk_any[64] = {};
-static std::mutex g_streamk_mu;
-int mm::streamk_ordered_admit(int dev, hipStream_t s, bool *admitted) {
-  *admitted = false;
-  if (dev < 0 || dev >= 64 || g_device_cus[dev] != 256) return 0;
+// Where any of this does not hold, the ticket is refused and the launcher runs the two-kernel teams form (same bits).
+namespace {
+struct StreamkDeviceState {
+  std::mutex mu;                     // per device: host threads driving different GPUs do not meet here
+  hipEvent_t event = nullptr;        // recorded behind the last hand-over launch
+  hipStream_t stream = nullptr;      // ... on this stream
+  bool any = false;
+};
+StreamkDeviceState g_streamk[64];
+}  // namespace
+
+mm::StreamkTicket::StreamkTicket(int dev, hipStream_t s) : device_(dev), stream_(s) {
+  if (dev < 0 || dev >= 64 || g_device_cus[dev] != 256) return;
   hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
   hipError_t e = hipStreamIsCapturing(s, &capture);
-  if (e != hipSuccess) return (int)e;
-  if (capture != hipStreamCaptureStatusNone) return 0;
+  if (e != hipSuccess) { error_ = (int)e; return; }
+  if (capture != hipStreamCaptureStatusNone) return;
   uint32_t mask[8] = {};
   e = hipExtStreamGetCUMask(s, 8, mask);
   if (e == hipSuccess) {
     int cus = 0;
     for (uint32_t w : mask) cus += __builtin_popcount(w);
-    if (cus != 256) return 0;
+    if (cus != 256) return;
   } else {
     (void)hipGetLastError();
-    if (s != nullptr) return 0;        // a stream whose mask cannot be read is treated as masked; the null stream has none of its own
+    if (s != nullptr) return;        // a stream whose mask cannot be read is treated as masked; the null stream has none of its own
   }
-  // From here to streamk_ordered_release() the device's stream-K ticket is held: wait-for-previous, launch and
-  // record-behind-it are one step, or two host threads on two streams could both wait for the SAME earlier event and
-  // then run side by side.
-  g_streamk_mu.lock();
-  if (!g_streamk_event[dev]) {
-    if ((e = hipEventCreateWithFlags(&g_streamk_event[dev], hipEventDisableTiming)) != hipSuccess) {
-      g_streamk_event[dev] = nullptr;
-      g_streamk_mu.unlock();
-      return (int)e;
-    }
+  // From here to the destructor the device's ticket is held: wait-for-previous, launch and record-behind-it are one step,
+  // or two host threads on two streams could both wait for the SAME earlier event and then run side by side.
+  StreamkDeviceState &st = g_streamk[dev];
+  st.mu.lock();
+  if (!st.event && (e = hipEventCreateWithFlags(&st.event, hipEventDisableTiming)) != hipSuccess) {
+    st.event = nullptr;
+    st.mu.unlock();
+    error_ = (int)e;
+    return;
   }
-  if (g_streamk_any[dev] && g_streamk_stream[dev] != s) {
-    if ((e = hipStreamWaitEvent(s, g_streamk_event[dev], 0)) != hipSuccess) { g_streamk_mu.unlock(); return (int)e; }
+  if (st.any && st.stream != s && (e = hipStreamWaitEvent(s, st.event, 0)) != hipSuccess) {
+    st.mu.unlock();
+    error_ = (int)e;
+    return;
   }
-  *admitted = true;
-  return 0;
+  admitted_ = true;
 }
-int mm::streamk_ordered_release(int dev, hipStream_t s, bool launched) {   // after an admitted launch attempt, ALWAYS
-  hipError_t e = hipSuccess;
-  if (launched) {
-    e = hipEventRecord(g_streamk_event[dev], s);
-    g_streamk_stream[dev] = s;
-    g_streamk_any[dev] = true;
+
+mm::StreamkTicket::~StreamkTicket() {
+  if (!admitted_) return;
+  StreamkDeviceState &st = g_streamk[device_];
+  if (launched_) {
+    (void)hipEventRecord(st.event, stream_);
+    st.stream = stream_;
+    st.any = true;
   }
-  g_streamk_mu.unlock();
-  return (int)e;
+  st.mu.unlock();
 }
+
 int mm::device_compute_units(int dev) { return dev >= 0 && dev < 64 && g_device_cus[dev] > 0 ? g_device_cus[dev] : 256; }
 
 int mm::workspace_release(int dev) {
@@ -754,8 +762,9 @@ const char *mm_kernel_name(const mm_config_t *cfg, unsigned n, unsigned k, unsig
                                                         "mfma_f32_64x64x32_w4x2_splitk8"};
         return small_split_names[splits];
       }
-      if (splits == 0) return "mfma_f32_128x128x32_w4x2_streamk";
-      if (splits == 9) return "mfma_f32_128x128x32_w4x2_streamk_fixup";
+      if (splits == 0) return "mfma_f32_128x128x32_w4x2_streamk";            // teams + fix-up kernel: what MM_PATH_AUTO runs
+      if (splits == 9) return "mfma_f32_128x128x32_w4x2_streamk_fixup";      // single ranges + fix-up kernel (cross-check)
+      if (splits == 10) return "mfma_f32_128x128x32_w4x2_streamk_handover";  // opt-in one-kernel form; the bits of `streamk`
       return splits > 1 ? split_names[splits] : mm::mfma_f32_name(v);
     }
     case FAM_MFMA_F64: return mm::mfma_f64_name(p);

@@ -323,6 +323,10 @@ __device__ __forceinline__ void tile_body(const float *__restrict__ A, const flo
       return;
     }
     const unsigned ccol = col0 + wn * 128 + 4 * lo;
+    unsigned ldv = ldc;
+    asm volatile("" : "+s"(ldv));   // opaque, as in rmw_interior: the 16 x TM row addresses (two registers each) must not be hoisted out
+                                    // of the chunk loop -- they would stay live across the main loop; in the VectorAddress twin of the
+                                    // 256 x 256 geometry that cost a spill
 #pragma unroll
     for (int mi = 0; mi < TM; ++mi) {
 #pragma unroll
@@ -330,7 +334,7 @@ __device__ __forceinline__ void tile_body(const float *__restrict__ A, const flo
         const unsigned ri = (r & 3) + 8 * (r >> 2) + 4 * hi;
         const unsigned row = row0 + wm * TM * 32 + (AT ? TM * ri + mi : mi * 32 + ri);
         if (ccol < Mst && row < Nst) {
-          f32x4 *dst = (f32x4 *)(Cst + (size_t)row * ldc + ccol);
+          f32x4 *dst = (f32x4 *)(Cst + (size_t)row * ldv + ccol);
           f32x4 v;
 #pragma unroll
           for (int tt = 0; tt < TN; ++tt) v[tt] = acc[mi][tt][r];
@@ -825,7 +829,9 @@ __global__ __launch_bounds__(G::THREADS, G::MIN_WAVES) void mfma_f32_streamk_ker
   }
 }
 
-// Stream-K with the combine inside the launch ("ordered hand-over": what f32_splitk = 0 and the shape-adaptive rule run; 9 = the fix-up kernel above, kept as its cross-check).  Same unit ranges.  Observation: every
+// Stream-K in TEAMS (what the shape-adaptive rule and f32_splitk = 0 run, as two kernels -- see HANDOVER below; 9 = the single-range
+// form above, kept as its cross-check), here first in its one-kernel form with the combine inside the launch ("ordered
+// hand-over", f32_splitk = 10, opt-in).  Same unit ranges.  Observation: every
 // segment of a tile other than its lowest-k one is the FIRST segment of the workgroup that owns it (a range enters a tile
 // from below only at its own start), and the lowest-k segment is the LAST thing its owner does.  So: the others write
 // their scratch slot and raise a flag right away; the owner of the lowest-k segment writes its sum to C, waits for those
@@ -835,9 +841,9 @@ __global__ __launch_bounds__(G::THREADS, G::MIN_WAVES) void mfma_f32_streamk_ker
 // property of the launch, not of the kernel: a waiting workgroup keeps its place on its CU, so every workgroup it waits
 // for must find a place without it leaving -- true when all 512 workgroups fit the chip at once (256 CUs x 2) next to
 // kernels that finish on their own, false on a CU-masked stream, on a partitioned device, or next to a second launch of
-// this kind (each holding places the other's producers need).  launch_streamk_ordered therefore only runs this kernel
-// after streamk_ordered_admit() (mm_capi.hip) has checked the device and the stream and ordered the launch behind the
-// previous one of its kind; everything else takes the two-kernel form above.  Visibility: the producer's stores, __syncthreads, one lane's agent-scope
+// this kind -- of ANY process sharing the device -- (each holding places the other's producers need).  launch_streamk_ordered therefore
+// only runs this kernel on request (f32_splitk 10) and under a StreamkTicket (mm_capi.hip), which checks the device and the stream and
+// orders the launch behind the previous one of its kind in this process; everything else takes the two-kernel teams form.  Visibility: the producer's stores, __syncthreads, one lane's agent-scope
 // release + s_waitcnt vmcnt(0) + relaxed agent store of the flag; the consumer's relaxed poll by one lane, agent-scope
 // acquire, __syncthreads, plain loads (MI355X_MICROARCH.md, inter-workgroup visibility: the valid forms).
 //
@@ -849,7 +855,12 @@ __global__ __launch_bounds__(G::THREADS, G::MIN_WAVES) void mfma_f32_streamk_ker
 // tile `lane` of the super-tile, and all of a team are at the same slab at the same time -- each A slab is wanted by sc
 // of them and each B slab by sr.  Per lane this is exactly the scheme above with `teams` ranges.  Tiles of a ragged
 // super-tile that fall outside the matrix are skipped by their lane (the same lane in every team, so no flag is missed).
-template <typename G>
+//
+// HANDOVER = false is the form MM_PATH_AUTO runs: the same teams, ranges and slots, but nobody waits -- the lowest-k part
+// of a cut tile goes to C, the other parts to their slots (plain stores, no flags), and streamk_teams_fixup_kernel below
+// adds the slots on top of C in the same ascending-k order.  Bit-identical to the hand-over form (the same additions in
+// the same order), residency-independent (no workgroup ever waits for another one), one more small kernel.
+template <typename G, bool HANDOVER>
 __global__ __launch_bounds__(G::THREADS, G::MIN_WAVES) void mfma_f32_streamk_ordered_kernel(
     const float *__restrict__ A, const float *__restrict__ B, float *__restrict__ C, unsigned N, unsigned K, unsigned M,
     unsigned tiles_n, unsigned tiles_m, unsigned spt, unsigned sr, unsigned sc, unsigned teams_per_xcd, unsigned teams,
@@ -874,10 +885,14 @@ __global__ __launch_bounds__(G::THREADS, G::MIN_WAVES) void mfma_f32_streamk_ord
     } else if (s0 > 0) {   // not the lowest-k segment: this workgroup's first segment -> its slot, then the flag
       float *slot = slots + (size_t)w * (G::BM * G::BN);
       float *base = (float *)((unsigned long long)slot - ((unsigned long long)row0 * G::BN + col0) * sizeof(float));
-      tile_body<G, false, true>(a, b, base, N, klen, M, K, G::BN, ~0u, ~0u, row0, col0);   // slot stores at agent scope
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every wavefront: its slot stores have reached the agent's coherence point
-      __syncthreads();
-      if (threadIdx.x == 0) __hip_atomic_store(flags + w, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // raised = holds this launch's epoch
+      tile_body<G, false, HANDOVER>(a, b, base, N, klen, M, K, G::BN, ~0u, ~0u, row0, col0);   // (hand-over: slot stores at agent scope)
+      if constexpr (HANDOVER) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every wavefront: its slot stores have reached the agent's coherence point
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(flags + w, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // raised = holds this launch's epoch
+      }
+    } else if constexpr (!HANDOVER) {   // the lowest-k segment of a split tile: into C; the fix-up kernel adds the others
+      tile_body<G, false>(a, b, C, N, klen, M, K, M, N, M, row0, col0);
     } else {               // the lowest-k segment of a split tile: this one into C, then the others on top in ascending k
       tile_body<G, false>(a, b, C, N, klen, M, K, M, N, M, row0, col0);
       const unsigned u_hi = st * spt + spt;
@@ -922,31 +937,112 @@ static TeamShape streamk_team_shape(unsigned tiles_n, unsigned tiles_m) {
   return {side(tiles_n), side(tiles_m)};
 }
 
-template <typename G>
-int launch_streamk(hipStream_t s, const Problem &p);   // the two-kernel form, below
+// The second kernel of the two-kernel teams form: one workgroup per tile of C.  A tile that one team's range holds whole
+// was finished by the main kernel; for a cut tile C already holds the lowest-k part, and the slots of the teams that own
+// the other parts (the next teams in range order, same lane) are added on top in ascending k -- the additions of the
+// hand-over form's gather, in its order, by its thread mapping.
+template <int BM, int BN, int THREADS>
+__global__ __launch_bounds__(THREADS) void streamk_teams_fixup_kernel(const float *__restrict__ slots, float *__restrict__ C, unsigned N,
+                                                                       unsigned M, unsigned tiles_n, unsigned tiles_m, unsigned spt,
+                                                                       unsigned sr, unsigned sc, unsigned teams) {
+  const unsigned tile_r = blockIdx.x % tiles_n, tile_c = blockIdx.x / tiles_n;
+  const unsigned lanes = sr * sc, st_rows = (tiles_n + sr - 1) / sr, st_cols = (tiles_m + sc - 1) / sc;
+  const unsigned st = (tile_c / sc) * st_rows + tile_r / sr, lane = tile_r % sr + (tile_c % sc) * sr;
+  const unsigned long long units = (unsigned long long)st_rows * st_cols * spt;
+  const unsigned u_lo = st * spt, u_hi = u_lo + spt;
+  unsigned t0 = (unsigned)((unsigned long long)u_lo * teams / units);     // the team whose range holds the tile's first unit
+  while (t0 + 1 < teams && sk_range_begin(units, t0 + 1, teams) <= u_lo) ++t0;
+  while (t0 > 0 && sk_range_begin(units, t0, teams) > u_lo) --t0;
+  unsigned t_end = t0 + 1;
+  while (t_end < teams && sk_range_begin(units, t_end, teams) < u_hi) ++t_end;
+  if (t_end == t0 + 1) return;                                            // one range holds the whole tile
+  const unsigned row0 = tile_r * BM, col0 = tile_c * BN;
+  constexpr int QUADS = BM * BN / 4 / THREADS;
+  f32x4 acc[QUADS];
+#pragma unroll
+  for (int i = 0; i < QUADS; ++i) {
+    const unsigned q = i * THREADS + threadIdx.x, row = row0 + q / (BN / 4), col = col0 + (q % (BN / 4)) * 4;
+    acc[i] = (row < N && col < M) ? *(const f32x4 *)(C + (size_t)row * M + col) : (f32x4)0.0f;
+  }
+  for (unsigned o = t0 + 1; o < t_end; ++o) {
+    const f32x4 *src = (const f32x4 *)(slots + (size_t)(o * lanes + lane) * (BM * BN));
+#pragma unroll
+    for (int i = 0; i < QUADS; ++i) acc[i] += src[i * THREADS + threadIdx.x];
+  }
+#pragma unroll
+  for (int i = 0; i < QUADS; ++i) {
+    const unsigned q = i * THREADS + threadIdx.x, row = row0 + q / (BN / 4), col = col0 + (q % (BN / 4)) * 4;
+    if (row < N && col < M) *(f32x4 *)(C + (size_t)row * M + col) = acc[i];
+  }
+}
 
+// How a problem is dealt out to teams: shared by both forms, so that they cut the same tiles at the same k.
+struct TeamPlan { unsigned tiles_n, tiles_m, spt, sr, sc, teams_per_xcd, teams; };
 template <typename G>
-int launch_streamk_ordered(hipStream_t s, const Problem &p) {
-  const unsigned tiles_n = (p.n + G::BM - 1) / G::BM, tiles_m = (p.m + G::BN - 1) / G::BN, spt = p.k / G::BK;
-  const TeamShape ts = streamk_team_shape(tiles_n, tiles_m);
-  const unsigned nwg = 512, teams_per_xcd = 64 / (ts.sr * ts.sc);   // 8 XCDs x 64 places
-  const unsigned long long super_tiles = (unsigned long long)(tiles_n / ts.sr) * (tiles_m / ts.sc), units = super_tiles * spt;
+static TeamPlan streamk_team_plan(const Problem &p) {
+  TeamPlan t;
+  t.tiles_n = (p.n + G::BM - 1) / G::BM; t.tiles_m = (p.m + G::BN - 1) / G::BN; t.spt = p.k / G::BK;
+  const TeamShape ts = streamk_team_shape(t.tiles_n, t.tiles_m);
+  t.sr = ts.sr; t.sc = ts.sc;
+  t.teams_per_xcd = 64 / (ts.sr * ts.sc);   // 8 XCDs x 64 places
+  const unsigned long long super_tiles = (unsigned long long)(t.tiles_n / ts.sr) * (t.tiles_m / ts.sc), units = super_tiles * t.spt;
   // every place gets a team when there is work for it: a team's range is at least 8 slabs (below that the fill and drain
   // of the rings outweigh the slabs -- the chunk floor of split-K) and a tile is cut at most 8 ways (the gather is serial
-  // in the owner of the lowest part, and a wait never aims further than 8 teams ahead)
-  const unsigned teams = (unsigned)std::max<unsigned long long>(1, std::min<unsigned long long>({8ull * teams_per_xcd, units / 8, 8 * super_tiles}));
+  // in the owner of the lowest part, and in the hand-over form a wait never aims further than 8 teams ahead)
+  t.teams = (unsigned)std::max<unsigned long long>(1, std::min<unsigned long long>({8ull * t.teams_per_xcd, units / 8, 8 * super_tiles}));
+  return t;
+}
+
+// Stream-K as MM_PATH_AUTO runs it (f32_splitk 0): teams, slots, and the fix-up kernel.  No workgroup waits for another
+// one, so it is sound wherever a kernel is -- next to any other launch of any process, on a CU-masked stream, on a
+// partition, inside a graph -- and its bits are the hand-over form's.
+template <typename G>
+int launch_streamk_teams(hipStream_t s, const Problem &p) {
+  const TeamPlan t = streamk_team_plan<G>(p);
+  const unsigned nwg = 512;
   static_assert(G::MIN_WAVES == 2, "two workgroups per CU: 64 places per XCD");
   static unsigned long long configured = 0;
-  if (int e = ensure_dynamic_lds((const void *)mfma_f32_streamk_ordered_kernel<G>, G::LDS_BYTES, configured)) return e;
+  if (int e = ensure_dynamic_lds((const void *)mfma_f32_streamk_ordered_kernel<G, false>, G::LDS_BYTES, configured)) return e;
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return (int)e;
   hipMemPool_t pool = nullptr;
   if (int rc = workspace_pool(dev, &pool)) return rc;
-  // the whole chip, an unmasked stream, no capture, and ordered behind the previous launch of this kind: else the two-kernel form
-  bool admitted = false;
-  if (int rc = streamk_ordered_admit(dev, s, &admitted)) return rc;
-  if (!admitted) return launch_streamk<G>(s, p);
+  float *slots = nullptr;
+  const size_t slot_bytes = (size_t)nwg * G::BM * G::BN * sizeof(float);
+  if ((e = hipMallocFromPoolAsync((void **)&slots, slot_bytes, pool, s)) != hipSuccess) return (int)e;
+  if (tuning(TUNE_DEBUG_POISON) == 1 && (e = hipMemsetAsync(slots, 0xFF, slot_bytes, s)) != hipSuccess) { (void)hipFreeAsync(slots, s); return (int)e; }   // NaN everywhere
+  (void)hipGetLastError();
+  hipLaunchKernelGGL((mfma_f32_streamk_ordered_kernel<G, false>), dim3(nwg), dim3(G::THREADS), G::LDS_BYTES, s, (const float *)p.a,
+                     (const float *)p.b, (float *)p.c, p.n, p.k, p.m, t.tiles_n, t.tiles_m, t.spt, t.sr, t.sc, t.teams_per_xcd, t.teams,
+                     slots, (unsigned long long *)nullptr, 0ull);
+  int rc = (int)hipGetLastError();
+  if (rc == 0 && t.teams > 1) {
+    hipLaunchKernelGGL((streamk_teams_fixup_kernel<G::BM, G::BN, G::THREADS>), dim3(t.tiles_n * t.tiles_m), dim3(G::THREADS), 0, s,
+                       (const float *)slots, (float *)p.c, p.n, p.m, t.tiles_n, t.tiles_m, t.spt, t.sr, t.sc, t.teams);
+    rc = (int)hipGetLastError();
+  }
+  const hipError_t f = hipFreeAsync(slots, s);
+  return rc ? rc : (int)f;
+}
+
+// The hand-over form (f32_splitk 10, opt-in): one kernel, the gather overlapped with other teams' work.  Needs the whole
+// chip to itself among launches of its kind IN EVERY PROCESS that shares the device -- the library can only order the ones
+// of this process (StreamkTicket, mm_capi.hip) -- which is why MM_PATH_AUTO no longer takes it (VERDICT r4
+// next 5).  Where the ticket is refused it runs the form above: same bits.
+template <typename G>
+int launch_streamk_ordered(hipStream_t s, const Problem &p) {
+  const TeamPlan t = streamk_team_plan<G>(p);
+  const unsigned nwg = 512;
+  static_assert(G::MIN_WAVES == 2, "two workgroups per CU: 64 places per XCD");
+  static unsigned long long configured = 0;
+  if (int e = ensure_dynamic_lds((const void *)mfma_f32_streamk_ordered_kernel<G, true>, G::LDS_BYTES, configured)) return e;
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return (int)e;
+  hipMemPool_t pool = nullptr;
+  if (int rc = workspace_pool(dev, &pool)) return rc;
+  // scratch first, the ticket last: only wait-for-previous, launch and record-behind-it happen while it is held
   float *slots = nullptr;
   void *flags = nullptr;
   unsigned long long epoch = 0;
@@ -954,18 +1050,23 @@ int launch_streamk_ordered(hipStream_t s, const Problem &p) {
   int rc = (int)hipMallocFromPoolAsync((void **)&slots, slot_bytes, pool, s);
   if (rc == 0 && tuning(TUNE_DEBUG_POISON) == 1) rc = (int)hipMemsetAsync(slots, 0xFF, slot_bytes, s);   // NaN everywhere
   if (rc == 0) rc = flags_alloc(dev, s, nwg * sizeof(unsigned long long), &flags, &epoch);
-  bool launched = false;
+  bool refused = false;
   if (rc == 0) {
-    (void)hipGetLastError();
-    hipLaunchKernelGGL((mfma_f32_streamk_ordered_kernel<G>), dim3(nwg), dim3(G::THREADS), G::LDS_BYTES, s, (const float *)p.a,
-                       (const float *)p.b, (float *)p.c, p.n, p.k, p.m, tiles_n, tiles_m, spt, ts.sr, ts.sc, teams_per_xcd, teams,
-                       slots, (unsigned long long *)flags, epoch);
-    rc = (int)hipGetLastError();
-    launched = rc == 0;
-  }
-  const int rel = streamk_ordered_release(dev, s, launched);   // the ticket taken by the admission, on every path
+    StreamkTicket ticket(dev, s);      // the whole chip, an unmasked stream, no capture, ordered behind the previous launch of this kind
+    rc = ticket.error();
+    refused = rc == 0 && !ticket.admitted();
+    if (rc == 0 && ticket.admitted()) {
+      (void)hipGetLastError();
+      hipLaunchKernelGGL((mfma_f32_streamk_ordered_kernel<G, true>), dim3(nwg), dim3(G::THREADS), G::LDS_BYTES, s, (const float *)p.a,
+                         (const float *)p.b, (float *)p.c, p.n, p.k, p.m, t.tiles_n, t.tiles_m, t.spt, t.sr, t.sc, t.teams_per_xcd, t.teams,
+                         slots, (unsigned long long *)flags, epoch);
+      rc = (int)hipGetLastError();
+      if (rc == 0) ticket.launched();
+    }
+  }   // ~StreamkTicket: records the event the next launch of this kind waits on, hands the ticket back
   const hipError_t f1 = flags ? hipFreeAsync(flags, s) : hipSuccess, f2 = slots ? hipFreeAsync(slots, s) : hipSuccess;
-  return rc ? rc : rel ? rel : f1 != hipSuccess ? (int)f1 : (int)f2;
+  if (rc == 0 && refused) return launch_streamk_teams<G>(s, p);
+  return rc ? rc : f1 != hipSuccess ? (int)f1 : (int)f2;
 }
 
 // C tile = sum of the scratch slots of the workgroups whose ranges cut it, ascending k.  One workgroup per tile; tiles that
@@ -1317,7 +1418,8 @@ int mfma_f32_resolve(const Problem &p, int variant) {
 // leave a quarter or more of the CUs without a workgroup (<= 192 tiles), K is cut into S = min(slots / tiles, K / 256, 8) chunks, the S copies of the tile grid run
 // side by side and a second kernel adds the S partial planes in ascending order -- deterministic, run to run and
 // whatever the placement, but a different summation order than the unsplit kernel (as accurate or better: shorter
-// chains).  f32_splitk: -1 this rule (and stream-K by streamk_wins), 0 stream-K, 1 neither, 2..8 that many chunks, 9 stream-K with the fix-up kernel (always only
+// chains).  f32_splitk: -1 this rule (and stream-K by streamk_wins), 0 stream-K (teams + fix-up kernel), 1 neither, 2..8 that many chunks, 9 stream-K in single ranges
+// with its fix-up kernel (cross-check), 10 stream-K with the hand-over inside the launch (opt-in; same bits as 0) (always only
 // for row-major A and variant 35).  Row slabs of a bigger job (Problem::n_total) never take stream-K: its unit ranges would
 // depend on the slab, and with them a row's summation order.
 int mfma_f32_splitk(const Problem &p, int variant) {
@@ -1331,7 +1433,7 @@ int mfma_f32_splitk(const Problem &p, int variant) {
   if (variant != 35) return 1;
   const int knob = tuning(TUNE_F32_SPLITK);
   const unsigned long long sk_units = (unsigned long long)((p.n + 127) / 128) * ((p.m + 127) / 128) * (p.k / 32);   // the kernels count units in 32 bits
-  if (knob == 0 || knob == 9) return (p.k % 32 == 0 && p.k >= 64 && sk_units < (1ull << 31)) ? knob : 1;   // stream-K forced: 0 = ordered hand-over (the one auto takes), 9 = fix-up kernel
+  if (knob == 0 || knob == 9 || knob == 10) return (p.k % 32 == 0 && p.k >= 64 && sk_units < (1ull << 31)) ? knob : 1;   // stream-K forced: 0 = teams + fix-up kernel (the one auto takes), 9 = single ranges + fix-up kernel, 10 = teams with the hand-over inside the launch
   const unsigned rows = p.n_total ? p.n_total : p.n;   // of the whole job (Problem::n_total)
   const unsigned long long tiles = (unsigned long long)((rows + 127) / 128) * ((p.m + 127) / 128);
   unsigned s;
@@ -1390,7 +1492,8 @@ int launch_mfma_f32(hipStream_t s, const Problem &p, int variant) {
     case 8: return sdma_fits(p, 16) ? launch_geo<T256x256>(s, p) : launch_geo<T256x256v>(s, p);
     case 35: {
       const int splits = mfma_f32_splitk(p, v);
-      if (splits == 0) return sdma_fits(p, 32) ? launch_streamk_ordered<T128x128>(s, p) : launch_streamk_ordered<T128x128v>(s, p);
+      if (splits == 0) return sdma_fits(p, 32) ? launch_streamk_teams<T128x128>(s, p) : launch_streamk_teams<T128x128v>(s, p);
+      if (splits == 10) return sdma_fits(p, 32) ? launch_streamk_ordered<T128x128>(s, p) : launch_streamk_ordered<T128x128v>(s, p);
       if (splits == 9) return sdma_fits(p, 32) ? launch_streamk<T128x128>(s, p) : launch_streamk<T128x128v>(s, p);
       return sdma_fits(p, 32) ? launch_geo<T128x128>(s, p, (unsigned)splits) : launch_geo<T128x128v>(s, p, (unsigned)splits);
     }

@@ -222,19 +222,24 @@ int mm_kernel_info(const mm_config_t *cfg, unsigned size_n, unsigned size_k, uns
 /* Tuning knobs for sweeps ("f32_variant", "f64_variant", "f16_variant", "i8_variant", "valu_variant", "split_variant",
  * "band_rows", "f32_splitk"; -1 = the library's own choice).  Kernel ids of this library: f32_variant 33 / 8 / 35 / 64 (the
  * geometries of the shape-adaptive pick) and 0 / 3 (cross-checks); f16_variant 200 / 100 / 11 / 0 / 4 / 5; i8_variant 200 /
- * 100 / 10 / 5 / 0; f64_variant 0-4 (4: the 64 x 64 geometry for small problems); f32_splitk 0 stream-K (ordered hand-over
- * inside the launch), 1 whole tiles, 2-8 K chunks, 9 stream-K with the fix-up kernel.  The hand-over form has workgroups
- * wait for each other inside one launch, so the library runs it only where that is sound -- a device reporting 256 compute
- * units, a stream without a CU mask, not under stream capture, and never two such launches at once (each is ordered behind
- * the previous one of its kind on the device with an event) -- and runs the fix-up form (9) everywhere else, also where
- * mm_kernel_name says "..._streamk": both are deterministic, their bits differ from each other within the fp32 contract.
+ * 100 / 10 / 5 / 0; f64_variant 0-4 (4: the 64 x 64 geometry for small problems); f32_splitk 1 whole tiles, 2-8 K chunks,
+ * 0 stream-K as MM_PATH_AUTO runs it (teams of workgroups, partial tiles through scratch slots, a small fix-up kernel adds
+ * them in ascending k: no workgroup ever waits for another one, so it is sound next to anything else on the device, on
+ * CU-masked streams, in graphs), 9 stream-K in single ranges with its own fix-up kernel (cross-check), 10 stream-K with the
+ * hand-over INSIDE the launch (opt-in; the bits of 0, a few per cent faster on some mid-size shapes).  Form 10 has workgroups
+ * wait for each other inside one launch; the library runs it only where that is sound as far as it can see -- a device
+ * reporting 256 compute units, a stream without a CU mask, not under stream capture, never two such launches of THIS
+ * PROCESS at once (each is ordered behind the previous one on the device with an event) -- and runs form 0 otherwise.  It
+ * cannot see other processes: whoever sets f32_splitk = 10 vouches that no second process runs such launches on the same
+ * device (two of them could each hold half the chip and wait for ever).
  * "debug_poison" = 1 fills the scratch that kernels hand partial tiles through with NaN before every launch (a read of
- * anything the launch did not write then shows in C; tests only).  Any other id is refused: the retired
- * schedules and the work-skipping ablations of the measurement history exist only in the lab build
- * (tools/lab/libmm_gemm_amd_lab.so, where "ablations" = 1 unlocks the latter).  Each knob is initialised ONCE from its
- * environment variable (MM_F32_VARIANT, ...) and changed only through this call afterwards; the launch path never reads
- * the environment.  The reference's counterpart is the build-time tile knob (CMakeLists.txt:18-20), which the host
- * binaries honour through -DMM_MEMORY_TILE_SIZE_N / _M (host/HostConfig.h: ApplyBuildTimeTile). */
+ * anything the launch did not write then shows in C; tests only).  "md_virtual_devices": see mm_gemm_multi_device.  Any
+ * other id is refused: the retired schedules and the work-skipping ablations of the measurement history exist only in the
+ * lab build (tools/lab/libmm_gemm_amd_lab.so, built on request, where "ablations" = 1 unlocks the latter).  Each knob is
+ * initialised ONCE from its environment variable (MM_F32_VARIANT, ...) and changed only through this call afterwards; the
+ * launch path never reads the environment.  The reference's counterpart is the build-time tile knob
+ * (CMakeLists.txt:18-20), which the host binaries honour through -DMM_MEMORY_TILE_SIZE_N / _M (host/HostConfig.h:
+ * ApplyBuildTimeTile). */
 int mm_tuning_set(const char *name, int value);
 int mm_tuning_get(const char *name, int *value);
 /* Message of the last failing call on this thread (static or thread-local storage). */

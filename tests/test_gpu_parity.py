@@ -221,13 +221,15 @@ def test_f32_split_k_for_small_problems_is_deterministic_and_accurate(shape, spl
                                           ((2304, 8448, 2304), False)],   # a workgroup's part of a tile > 4128 k: the chain is flushed INTO the scratch slot
                          ids=lambda v: "x".join(map(str, v)) if isinstance(v, tuple) else ("forced" if v else "auto"))
 def test_f32_stream_k_for_partial_rounds_is_deterministic_and_accurate(shape, forced):
-    """Round 3: problems of a few partial rounds of 128 x 128 tiles are dealt out to 512 persistent workgroups in equal
-    ranges of (tile, slab) units -- to teams of up to 4 x 4 workgroups on neighbouring tiles, so that an XCD's L2 still shares
-    the slabs.  A tile cut by a range boundary is finished inside the launch: the other parts go to scratch slots and raise a
-    flag, the owner of the lowest-k part writes C and adds the slots on top in ascending k.  Same bits on every launch;
-    inside the fp32 bound; picked by the shape-adaptive rule where it pays (`auto` cases) and forcible through
-    f32_splitk = 0 (ragged N / M, K of 3 slabs, ranges shorter than a tile, one tile cut 512 ways).  f32_splitk = 9 is
-    the two-kernel form (slots for every part, a fix-up kernel adds them): an independent implementation of the same idea."""
+    """Problems of a few partial rounds of 128 x 128 tiles are dealt out to 512 persistent workgroups in equal ranges of
+    (tile, slab) units -- to teams of up to 4 x 4 workgroups on neighbouring tiles, so that an XCD's L2 still shares the
+    slabs.  A tile cut by a range boundary: the lowest-k part goes to C, the other parts to scratch slots, and the slots
+    are added on top in ascending k -- by a small second kernel in the form MM_PATH_AUTO runs (f32_splitk 0; round 5: no
+    workgroup ever waits for another one), inside the launch behind epoch flags in the opt-in hand-over form
+    (f32_splitk 10).  The two forms perform the same additions in the same order: BIT-IDENTICAL.  Same bits on every
+    launch; inside the fp32 bound; picked by the shape-adaptive rule where it pays (`auto` cases) and forcible (ragged
+    N / M, K of 3 slabs, ranges shorter than a tile, one tile cut 512 ways).  f32_splitk = 9 is the single-range form
+    with its own fix-up kernel: an independent implementation of the same idea (different cut points, different bits)."""
     n, k, m = shape
     rng = np.random.default_rng(k + n)
     a = rng.uniform(-3, 10, size=(n, k)).astype(np.float32)
@@ -241,6 +243,9 @@ def test_f32_stream_k_for_partial_rounds_is_deterministic_and_accurate(shape, fo
         name = g.kernel_name(g.make_config("float"), n, k, m)
         runs = [g.matmul_capi(a, b)[0] for _ in range(3)]
         g.set_tuning("f32_variant", 35)
+        g.set_tuning("f32_splitk", 10)
+        name_handover = g.kernel_name(g.make_config("float"), n, k, m)
+        c_handover = [g.matmul_capi(a, b)[0] for _ in range(2)]
         g.set_tuning("f32_splitk", 9)
         name_fixup = g.kernel_name(g.make_config("float"), n, k, m)
         c_fixup, _ = g.matmul_capi(a, b)
@@ -250,18 +255,20 @@ def test_f32_stream_k_for_partial_rounds_is_deterministic_and_accurate(shape, fo
         g.set_tuning("f32_splitk", -1)
         g.set_tuning("f32_variant", -1)
     assert name == "mfma_f32_128x128x32_w4x2_streamk", name
+    assert name_handover == "mfma_f32_128x128x32_w4x2_streamk_handover", name_handover
     assert name_fixup == "mfma_f32_128x128x32_w4x2_streamk_fixup", name_fixup
     c1 = runs[0]
     assert np.array_equal(c1, runs[1]) and np.array_equal(c1, runs[2])
+    assert np.array_equal(c1, c_handover[0]) and np.array_equal(c1, c_handover[1]), "two-kernel teams form != hand-over form"
     # the bar first (BASELINE.json north_star, applied normwise on this mixed-sign data) ...
-    for what, c in (("ordered hand-over", c1), ("fix-up kernel", c_fixup), ("unsplit", c_one)):
+    for what, c in (("teams + fix-up", c1), ("single ranges + fix-up", c_fixup), ("unsplit", c_one)):
         _bounds.north_star(_bounds.normwise(c, exact, scale), f"{what} {n}x{k}x{m}")
     # ... then the self-imposed guards: chain-length aware (a workgroup's part of a tile can be a chain of up to 4096 k
     # before it is flushed; measured 2.2e-6 at K = 8448, 1.4-1.6e-6 at K <= 2304)
-    _bounds.guard(_bounds.normwise(c1, exact, scale), _bounds.f32_chain_guard(k), "ordered hand-over vs exact")
-    _bounds.guard(_bounds.normwise(c_fixup, exact, scale), _bounds.f32_chain_guard(k), "fix-up kernel vs exact")
-    _bounds.guard(_bounds.normwise(c1, c_one, scale), 5e-6, "ordered hand-over vs unsplit")
-    _bounds.guard(_bounds.normwise(c1, c_fixup, scale), 5e-6, "ordered hand-over vs fix-up kernel")
+    _bounds.guard(_bounds.normwise(c1, exact, scale), _bounds.f32_chain_guard(k), "teams + fix-up vs exact")
+    _bounds.guard(_bounds.normwise(c_fixup, exact, scale), _bounds.f32_chain_guard(k), "single ranges + fix-up vs exact")
+    _bounds.guard(_bounds.normwise(c1, c_one, scale), 5e-6, "teams + fix-up vs unsplit")
+    _bounds.guard(_bounds.normwise(c1, c_fixup, scale), 5e-6, "teams + fix-up vs single ranges + fix-up")
 
 
 def test_f32_stream_k_flags_need_no_clearing_between_launches_and_survive_a_release():
@@ -277,20 +284,28 @@ def test_f32_stream_k_flags_need_no_clearing_between_launches_and_survive_a_rele
         b = torch.empty((k, m), device=dev).uniform_(-3, 10, generator=torch.Generator(device=dev).manual_seed(30 + i))
         assert g.kernel_name(g.make_config("float"), n, k, m).endswith("streamk")
         ops.append((a, b))
-        alone.append(g.matmul(a, b).clone())
+        alone.append(g.matmul(a, b).clone())        # the two-kernel form MM_PATH_AUTO runs: the hand-over form must give its bits
     torch.cuda.synchronize()
-    for round_ in range(3):
-        for rep in range(20):
-            for i, (a, b) in enumerate(ops):
-                assert torch.equal(g.matmul(a, b), alone[i]), (round_, rep, shapes[i])
-        torch.cuda.synchronize()
-        g._check(g.lib().mm_release_workspace(0))
+    g.set_tuning("f32_variant", 35)
+    g.set_tuning("f32_splitk", 10)                  # the opt-in hand-over form: the one with flags
+    try:
+        for round_ in range(3):
+            for rep in range(20):
+                for i, (a, b) in enumerate(ops):
+                    assert torch.equal(g.matmul(a, b), alone[i]), (round_, rep, shapes[i])
+            torch.cuda.synchronize()
+            g._check(g.lib().mm_release_workspace(0))
+    finally:
+        g.set_tuning("f32_variant", -1)
+        g.set_tuning("f32_splitk", -1)
 
 
-def test_f32_stream_k_launches_sharing_the_chip_make_progress_and_keep_their_bits():
-    """The ordered hand-over waits inside the kernel (a workgroup on flags of workgroups with higher ids).  Two such launches
-    on two streams, plus a third stream of whole-tile launches, compete for the same CUs, so neither has all of its
-    workgroups resident: each must still finish (waits only ever aim a bounded distance ahead in dispatch order) and give
+@pytest.mark.parametrize("form", ["two_kernel", "handover"])
+def test_f32_stream_k_launches_sharing_the_chip_make_progress_and_keep_their_bits(form):
+    """Two stream-K launches on two streams, plus a third stream of whole-tile launches, compete for the same CUs, so
+    neither has all of its workgroups resident.  two_kernel (what MM_PATH_AUTO runs): nobody waits inside a kernel, so
+    there is nothing to go wrong.  handover (f32_splitk 10, opt-in): a workgroup waits on flags of workgroups with higher
+    ids, and the library orders such launches one behind the other (StreamkTicket): each must still finish and give
     the bits it gives alone.  Run under a watchdog: a hang here would otherwise take the box down with it."""
     import torch
     dev = torch.device("cuda:0")
@@ -306,10 +321,17 @@ def test_f32_stream_k_launches_sharing_the_chip_make_progress_and_keep_their_bit
     torch.cuda.synchronize()
     streams = [torch.cuda.Stream() for _ in shapes]
     outs = [[] for _ in shapes]
-    for rep in range(25):
-        for i, (a, b) in enumerate(ops):
-            with torch.cuda.stream(streams[i]):
-                outs[i].append(g.matmul(a, b))
+    try:
+        for rep in range(25):
+            for i, (a, b) in enumerate(ops):
+                stream_k = form == "handover" and names[i].endswith("streamk")
+                g.set_tuning("f32_variant", 35 if stream_k else -1)      # (read when the launch is enqueued)
+                g.set_tuning("f32_splitk", 10 if stream_k else -1)
+                with torch.cuda.stream(streams[i]):
+                    outs[i].append(g.matmul(a, b))
+    finally:
+        g.set_tuning("f32_variant", -1)
+        g.set_tuning("f32_splitk", -1)
     done = torch.cuda.Event()
     for st in streams:
         torch.cuda.current_stream().wait_stream(st)

@@ -1,15 +1,17 @@
-"""Stress of the stream-K hand-over (gemm_hls_amd/csrc/mm_mfma_f32.hip: mfma_f32_streamk_ordered_kernel) -- partial tiles
-pass from workgroup to workgroup INSIDE a launch through scratch slots and epoch flags.  What a clean run cannot see:
+"""Stress of stream-K's partial-tile traffic (gemm_hls_amd/csrc/mm_mfma_f32.hip: mfma_f32_streamk_ordered_kernel) in BOTH of
+its forms -- `two_kernel` (what MM_PATH_AUTO runs since round 5: slots, then a fix-up kernel; nobody waits inside a kernel)
+and `handover` (f32_splitk 10, opt-in: partial tiles pass from workgroup to workgroup INSIDE a launch through scratch slots
+and epoch flags).  What a clean run cannot see:
 
   * a stale read of a slot that an EARLIER launch of the same operands wrote is bit-identical to the right answer.  So
     every launch here runs with the library's `debug_poison` knob: the slot pool is filled with NaN first, and a read of
     anything this launch did not write (or wrote too late) puts NaN into C; shapes alternate so that a slot's previous
     contents never belong to the same tile; the whole matrix is compared, bit for bit, with the result of an unloaded run,
     which is itself checked against fp64;
-  * forward progress: a workgroup waiting inside the launch holds its CU.  The library admits the hand-over form only on
-    the whole chip, unmasked, outside capture and one such launch at a time (mm_capi.hip: streamk_ordered_admit); a
-    CU-masked stream must get the two-kernel form -- run in a child process under a watchdog, because the failure mode
-    of getting it wrong is a GPU that never comes back.
+  * forward progress: a workgroup waiting inside the launch holds its CU.  The library runs the hand-over form only on
+    request, on the whole chip, unmasked, outside capture and one such launch at a time (mm_capi.hip: StreamkTicket); a
+    CU-masked stream must get the two-kernel form even then -- run in a child process under a watchdog, because the
+    failure mode of getting it wrong is a GPU that never comes back.
 
 Reference semantics kept: one deterministic k-ordered result per element (kernel/Compute.cpp:108-142)."""
 import os
@@ -25,7 +27,7 @@ import gemm_hls_amd as g
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-# (shape, forced): auto = the shape-adaptive rule takes stream-K by itself; forced = f32_splitk 0 on the 128 x 128 geometry
+# (shape, forced): auto = the shape-adaptive rule takes stream-K by itself; forced = f32_splitk 0 / 10 on the 128 x 128 geometry
 CASES = [((2304, 256, 2304), False), ((2560, 512, 2560), False), ((3584, 256, 3584), False), ((2432, 288, 3712), False),
          ((2341, 2304, 2304), True),      # ragged N, a tile cut several ways
          ((640, 12352, 384), True),       # 15 tiles x 386 slabs: a part of a tile longer than 2 x 4096 k -> three flushes INTO its slot
@@ -39,13 +41,15 @@ def _knobs():
         g.set_tuning(knob, -1)
 
 
-def _run(a, b, forced):
-    g.set_tuning("f32_variant", 35 if forced else -1)
-    g.set_tuning("f32_splitk", 0 if forced else -1)
+def _run(a, b, forced, form="two_kernel"):
+    handover = form == "handover"
+    g.set_tuning("f32_variant", 35 if (forced or handover) else -1)
+    g.set_tuning("f32_splitk", 10 if handover else (0 if forced else -1))
     return g.matmul(a, b)
 
 
-def test_poisoned_slots_alternating_shapes_under_background_load():
+@pytest.mark.parametrize("form", ["two_kernel", "handover"])
+def test_poisoned_slots_alternating_shapes_under_background_load(form):
     import torch
     dev = torch.device("cuda:0")
     ops, clean = [], []
@@ -55,7 +59,7 @@ def test_poisoned_slots_alternating_shapes_under_background_load():
         g.set_tuning("f32_variant", 35 if forced else -1)
         g.set_tuning("f32_splitk", 0 if forced else -1)
         assert g.kernel_name(g.make_config("float"), n, k, m) == "mfma_f32_128x128x32_w4x2_streamk", (n, k, m)
-        c = _run(a, b, forced).clone()
+        c = _run(a, b, forced, form).clone()
         exact = a.double() @ b.double()
         scale = a.double().abs() @ b.double().abs()
         err = float(((c.double() - exact).abs() / scale).max())
@@ -71,7 +75,7 @@ def test_poisoned_slots_alternating_shapes_under_background_load():
     g.set_tuning("debug_poison", 1)
     launches, bad = 0, []
     order = np.random.default_rng(7)
-    for rep in range(300):
+    for rep in range(300 if form == "two_kernel" else 150):
         with torch.cuda.stream(side):
             if rep % 3 == 0:
                 noise.add_(1.0)
@@ -79,7 +83,7 @@ def test_poisoned_slots_alternating_shapes_under_background_load():
                 torch.mm(na, nb)
         for i in order.permutation(len(ops)):        # a slot's previous contents come from another shape's tiles
             a, b, forced = ops[i]
-            c = _run(a, b, forced)
+            c = _run(a, b, forced, form)
             launches += 1
             if not torch.equal(c, clean[i]):
                 nan = int(torch.isnan(c).sum())
@@ -88,7 +92,7 @@ def test_poisoned_slots_alternating_shapes_under_background_load():
             break
     torch.cuda.synchronize()
     assert not bad, f"hand-over read what this launch had not written (rep, shape, NaNs, differing elements): {bad[:4]}"
-    assert launches >= 2000, launches
+    assert launches >= (2000 if form == "two_kernel" else 1000), launches
 
 
 def test_poison_knob_really_poisons_and_the_fixup_form_passes_it_too():
@@ -102,19 +106,23 @@ def test_poison_knob_really_poisons_and_the_fixup_form_passes_it_too():
     a = torch.empty((n, k), device=dev).uniform_(-3, 10)
     b = torch.empty((k, m), device=dev).uniform_(-3, 10)
     g.set_tuning("f32_variant", 35)
-    g.set_tuning("f32_splitk", 9)
-    plain = g.matmul(a, b).clone()
-    g.set_tuning("debug_poison", 1)
-    for _ in range(20):
-        assert torch.equal(g.matmul(a, b), plain)
-    assert not bool(torch.isnan(plain).any())
+    for form in (9, 0):
+        g.set_tuning("debug_poison", -1)
+        g.set_tuning("f32_splitk", form)
+        plain = g.matmul(a, b).clone()
+        g.set_tuning("debug_poison", 1)
+        for _ in range(20):
+            assert torch.equal(g.matmul(a, b), plain), form
+        assert not bool(torch.isnan(plain).any())
 
 
-def test_two_host_threads_on_two_streams_keep_their_bits_and_finish():
-    """Two host threads, each with its own stream, launch stream-K shapes at the same time (poisoned slots).  The library
-    takes a per-device ticket from the admission of a hand-over launch to the event recorded behind it, so the two
-    threads' launches are ordered one behind the other on the GPU instead of sharing it (each holding places the other's
-    producers need); a third thread keeps whole-tile launches running next to them.  Same bits as alone, under a watchdog."""
+@pytest.mark.parametrize("form", ["two_kernel", "handover"])
+def test_two_host_threads_on_two_streams_keep_their_bits_and_finish(form):
+    """Two host threads, each with its own stream, launch stream-K shapes at the same time (poisoned slots); a third
+    thread keeps whole-tile launches running next to them.  handover (MM_F32_SPLITK=10 semantics, set through the knob for
+    the whole test: the whole-tile thread's 2048^3 then runs as forced stream-K too, which only adds to the contention):
+    the library takes a per-device ticket from the admission of a hand-over launch to the event recorded behind it, so the
+    launches are ordered one behind the other on the GPU instead of sharing it.  Same bits as alone, under a watchdog."""
     import threading
     import time
     import torch
@@ -128,6 +136,11 @@ def test_two_host_threads_on_two_streams_keep_their_bits_and_finish():
         ops.append((a, b))
         alone.append(g.matmul(a, b).clone())
     wa, wb = torch.rand((2048, 2048), device=dev), torch.rand((2048, 2048), device=dev)
+    if form == "handover":
+        g.set_tuning("f32_variant", 35)
+        g.set_tuning("f32_splitk", 10)
+        for i, op in enumerate(ops):
+            assert torch.equal(g.matmul(*op), alone[i])      # the hand-over form gives the two-kernel form's bits
     whole = g.matmul(wa, wb).clone()
     torch.cuda.synchronize()
     g.set_tuning("debug_poison", 1)
@@ -174,10 +187,9 @@ n, k, m = 2341, 2304, 2304
 a = torch.empty((n, k), device=dev).uniform_(-3, 10)
 b = torch.empty((k, m), device=dev).uniform_(-3, 10)
 assert g.kernel_name(g.make_config("float"), n, k, m).endswith("streamk")
-ordered = g.matmul(a, b).clone()
-g.set_tuning("f32_variant", 35); g.set_tuning("f32_splitk", 9)
-fixup = g.matmul(a, b).clone()
-g.set_tuning("f32_variant", -1); g.set_tuning("f32_splitk", -1)
+two_kernel = g.matmul(a, b).clone()
+g.set_tuning("f32_variant", 35); g.set_tuning("f32_splitk", 10)      # ask for the hand-over form ...
+handover = g.matmul(a, b).clone()
 torch.cuda.synchronize()
 mask = (ctypes.c_uint32 * 8)(*([0x0000FFFF] * 8))          # half of every XCD's CUs: 128 places for 512 workgroups
 stream = ctypes.c_void_p()
@@ -189,8 +201,7 @@ cfg = g.make_config("float")
 for _ in range(5):
     g._check(g.lib().mm_gemm_enqueue(stream, ctypes.byref(cfg), a.data_ptr(), b.data_ptr(), out.data_ptr(), n, k, m))
 torch.cuda.synchronize()
-print("masked==fixup", bool(torch.equal(out, fixup)), "masked==ordered", bool(torch.equal(out, ordered)),
-      "ordered==fixup", bool(torch.equal(ordered, fixup)))
+print("masked==two_kernel", bool(torch.equal(out, two_kernel)), "handover==two_kernel", bool(torch.equal(handover, two_kernel)))
 """
 
 
@@ -200,6 +211,5 @@ def test_cu_masked_stream_gets_the_two_kernel_form_and_finishes():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     if "SKIP" in r.stdout:
         pytest.skip(r.stdout.strip())
-    assert "masked==fixup True" in r.stdout, r.stdout
-    if "ordered==fixup False" in r.stdout:
-        assert "masked==ordered False" in r.stdout, r.stdout
+    # ... on a CU-masked stream the ticket is refused and the two-kernel form runs (it finished: we are here), same bits
+    assert "masked==two_kernel True" in r.stdout and "handover==two_kernel True" in r.stdout, r.stdout

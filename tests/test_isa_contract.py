@@ -1,5 +1,7 @@
 """The machine code of the hand-synchronised stream-K kernel (gemm_hls_amd/csrc/mm_mfma_f32.hip:
-mfma_f32_streamk_ordered_kernel), checked on the gfx950 ISA hipcc emits for the shipped source with the build's flags.
+mfma_f32_streamk_ordered_kernel<G, HANDOVER = true>, the opt-in one-kernel form, f32_splitk 10), checked on the gfx950 ISA
+hipcc emits for the shipped source with the build's flags -- and of its HANDOVER = false twin, the form MM_PATH_AUTO runs,
+which must contain NO inter-workgroup synchronisation at all (no flag store, no poll, no sleep, no invalidate).
 
 The kernel hands partial tiles from one workgroup to another INSIDE a launch through scratch slots and epoch flags, with
 hand-written agent-scope (sc1) stores.  Its memory ordering is a contract between the source (inline asm included) and
@@ -27,6 +29,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gemm_hls_amd", "csrc", "mm_mfma_f32.hip")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+_ALL = {}
 
 
 @pytest.fixture(scope="module")
@@ -53,7 +56,17 @@ def ordered_kernels():
             kernels[name] = body
             name = None
     picked = {k: v for k, v in kernels.items() if "mfma_f32_streamk_ordered_kernel" in k}
-    assert len(picked) == 2, list(kernels)           # scalar-base DMA and vector-address twins
+    assert len(picked) == 4, list(kernels)           # (scalar-base DMA, vector-address) x (hand-over, two-kernel)
+    _ALL["kernels"] = kernels
+    _ALL["metadata"] = r.stdout
+    handover = {k: v for k, v in picked.items() if "Lb1EEEv" in k}      # <G, true>
+    assert len(handover) == 2, list(picked)
+    return handover
+
+
+def _two_kernel_forms(ordered_kernels):
+    picked = {k: v for k, v in _ALL["kernels"].items() if "mfma_f32_streamk_ordered_kernel" in k and k not in ordered_kernels}
+    assert len(picked) == 2 and len(ordered_kernels) == 2, (list(picked), list(ordered_kernels))
     return picked
 
 
@@ -103,3 +116,26 @@ def test_no_atomics_on_data_and_no_whole_cache_write_back(ordered_kernels):
     for name, body in ordered_kernels.items():
         assert not any("atomic" in t for t in body), name
         assert not any(_is("buffer_wbl2", t) for t in body), name      # slots go out with sc1 stores, not by writing the L2 back
+
+
+def test_the_default_stream_k_form_has_no_inter_workgroup_synchronisation(ordered_kernels):
+    """mfma_f32_streamk_ordered_kernel<G, false> + streamk_teams_fixup_kernel is what MM_PATH_AUTO runs:
+    no workgroup may wait for another one -- no flag store, no polling load, no sleep, no invalidate, no agent-scope store."""
+    for name, body in _two_kernel_forms(ordered_kernels).items():
+        assert not any(_is("global_store_dwordx2", t) for t in body), name
+        assert not any(_is("global_load_dwordx2", t) and t.endswith("sc1") for t in body), name
+        assert not any(_is("s_sleep", t) for t in body), name
+        assert not any(t.startswith("buffer_inv") for t in body), name
+        assert not any(t.startswith("global_store") and t.endswith("sc1") for t in body), name
+        assert not any("atomic" in t for t in body), name
+    fix = [k for k in _ALL["kernels"] if "streamk_teams_fixup_kernel" in k]
+    assert len(fix) == 1 and not any("atomic" in t or _is("s_sleep", t) for t in _ALL["kernels"][fix[0]])
+
+
+def test_no_shipped_matrix_core_kernel_of_this_unit_spills(ordered_kernels):
+    """No scratch in any kernel of mm_mfma_f32.hip (the VectorAddress twin of the 256 x 256 geometry once
+    kept 8 bytes of its addresses in scratch): no scratch_ instruction, and a zero private segment in the metadata."""
+    for name, body in _ALL["kernels"].items():
+        assert not any(t.startswith("scratch_") for t in body), name
+    sizes = re.findall(r"\.private_segment_fixed_size:\s*(\d+)", _ALL["metadata"])
+    assert sizes and all(int(x) == 0 for x in sizes), sizes

@@ -393,6 +393,28 @@ def _ordered_replay(tiles_n, tiles_m, spt):
         assert k == spt
     cut = {t for (t, _, _) in slot_of.values()}
     assert cut == set(lowest) and not (cut & whole) and len(cut | whole) == tiles_n * tiles_m
+    # The two-kernel form (HANDOVER = false, what MM_PATH_AUTO runs) does the gather in streamk_teams_fixup_kernel: one
+    # workgroup per tile re-derives, from the tile alone, which slots to add.  It must find exactly what the hand-over
+    # form's waiting workgroup gathered: nothing for a whole tile, the same slots in the same order for a cut one.
+    for tile_c in range(tiles_m):
+        for tile_r in range(tiles_n):
+            st = (tile_c // sc) * st_rows + tile_r // sr
+            lane = tile_r % sr + (tile_c % sc) * sr
+            u_lo, u_hi = st * spt, st * spt + spt
+            t0 = u_lo * teams // units
+            while t0 + 1 < teams and _sk_begin(units, t0 + 1, teams) <= u_lo:
+                t0 += 1
+            while t0 > 0 and _sk_begin(units, t0, teams) > u_lo:
+                t0 -= 1
+            t_end = t0 + 1
+            while t_end < teams and _sk_begin(units, t_end, teams) < u_hi:
+                t_end += 1
+            sources = [o * lanes + lane for o in range(t0 + 1, t_end)]
+            if (tile_r, tile_c) in whole:
+                assert sources == []
+            else:
+                assert sources == lowest[(tile_r, tile_c)][1]
+                assert covered[((tile_r, tile_c), 0)] == t0 * lanes + lane       # C holds the part of the team the fix-up starts from
     return sr, sc, teams
 
 

@@ -1,4 +1,5 @@
-"""Stream-K rate sweep: shape-adaptive pick / whole tiles only / ordered hand-over (f32_splitk 0) / fix-up kernel (9)."""
+"""Stream-K rate sweep: shape-adaptive pick / whole tiles only / teams + fix-up kernel (f32_splitk 0, what auto runs) / teams with
+the hand-over inside the launch (10, opt-in) / single ranges + fix-up kernel (9)."""
 import sys
 sys.path.insert(0, "tools"); from _lib import g
 import sweep
@@ -13,4 +14,4 @@ def rate(s, sk, var):
 for s in sizes:
     t = (s + 127) // 128
     name = g.kernel_name(g.make_config("float"), s, s, s)
-    print(s, f"{t}x{t} tiles: auto", rate(s, -1, -1), "whole tiles", rate(s, 1, -1), "stream-K ordered", rate(s, 0, 35), "stream-K fix-up", rate(s, 9, 35), " auto =", name, flush=True)
+    print(s, f"{t}x{t} tiles: auto", rate(s, -1, -1), "whole tiles", rate(s, 1, -1), "stream-K teams+fixup", rate(s, 0, 35), "hand-over", rate(s, 10, 35), "single-range fix-up", rate(s, 9, 35), " auto =", name, flush=True)
