@@ -169,13 +169,77 @@ def replayed_counters(kernel_name, shape, dtype=None):
     return out
 
 
+LIVE_KERNEL = "mfma_f32_256x256x16_w8_flush4096"   # f32_variant 8: what the PMC child passes pin and what the headline must have run
+
+
+def live_counters(kernel_name, shape, avg_launch_ms, timeout=240):
+    """Counters of the headline kernel MEASURED IN THIS RUN: three rocprofv3 child passes of
+    tools/sweep.py on the same shape -- FETCH_SIZE, WRITE_SIZE (separate --pmc passes, gfx950 correction: fetch doubled,
+    MI355X_MICROARCH.md HBM section) and SQ_VALU_MFMA_BUSY_CYCLES + GRBM_GUI_ACTIVE -- each with --kernel-trace only.  Run
+    after every timed leg (the passes serialise and slow the kernel).  Returns None when rocprofv3 is absent, the kernel is
+    not the one the passes pin, or a pass fails: the caller then falls back to the replayed figures."""
+    import shutil
+    import tempfile
+    if os.environ.get("MM_BENCH_NO_PMC") or shutil.which("rocprofv3") is None or kernel_name != LIVE_KERNEL or list(shape) != [SIZE] * 3:
+        return None
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    workdir = tempfile.mkdtemp(prefix="mm_bench_pmc_", dir="/tmp")
+    try:
+        import csv
+        import glob
+        import subprocess
+
+        def one_pass(counters, tag):
+            d = os.path.join(workdir, tag)
+            os.makedirs(d, exist_ok=True)
+            cmd = ["rocprofv3", "--pmc", *counters, "--kernel-trace", "-d", d, "-o", "pmc", "--output-format", "csv", "--",
+                   sys.executable, os.path.join(ROOT, "tools", "sweep.py"), "f32", "--sizes", str(SIZE), "--reps", "2", "--variants", "8"]
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=timeout)
+            if r.returncode != 0:
+                raise RuntimeError(f"rocprofv3 {tag}: rc {r.returncode}: {(r.stderr or r.stdout)[-300:]}")
+            vals, durs = {}, []
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if "mfma_f32_kernel" in row.get("Kernel_Name", ""):
+                        vals.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+            for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if "mfma_f32_kernel" in row.get("Kernel_Name", ""):
+                        durs.append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+            if not vals:
+                raise RuntimeError(f"rocprofv3 {tag}: no counter rows for the kernel")
+            return {k: sum(v) / len(v) for k, v in vals.items()}, (sum(durs) / len(durs) if durs else None), max(len(v) for v in vals.values())
+
+        t0 = time.perf_counter()
+        fetch, _, launches = one_pass(["FETCH_SIZE"], "fetch")
+        write, _, _ = one_pass(["WRITE_SIZE"], "write")
+        busy, dur_ns, _ = one_pass(["SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"], "mfma")
+        traffic = 2.0 * fetch["FETCH_SIZE"] * 1024.0 + write["WRITE_SIZE"] * 1024.0
+        gui = busy["GRBM_GUI_ACTIVE"] / 8.0          # rocprofv3 sums the 8 XCDs
+        out = {"traffic": traffic, "fetch_bytes_corrected": 2.0 * fetch["FETCH_SIZE"] * 1024.0, "write_bytes": write["WRITE_SIZE"] * 1024.0,
+               "mfma_util_pct": round(100.0 * busy["SQ_VALU_MFMA_BUSY_CYCLES"] / (gui * 1024), 2),
+               "achieved_fabric_GBps": round(traffic / (1e-3 * avg_launch_ms) / 1e9, 1),
+               "counters_measured_in_this_run": True, "launches_profiled_per_pass": launches,
+               "counter_passes_s": round(time.perf_counter() - t0, 1),
+               "counters_how": "3 rocprofv3 child passes (--pmc X --kernel-trace) of tools/sweep.py f32 16384 on this box after the timed legs: "
+                               "FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, KiB -> bytes per launch; MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs)"}
+        if dur_ns:
+            out["profiled_clock_GHz"] = round(gui / dur_ns, 3)
+            out["profiled_launch_ms"] = round(dur_ns * 1e-6, 3)
+        return out
+    except Exception as exc:   # a counter pass must never take the headline line down with it
+        sys.stderr.write(f"[bench] live counters unavailable: {exc!r}\n")
+        return None
+    finally:
+        shutil.rmtree(workdir, ignore_errors=True)
+
+
 def attach_replayed(roofline, kernel_name, shape, dtype=None):
     """Adds the replayed counters to a roofline object; `achieved_fabric_GBps` = replayed bytes per launch over the
     launch time measured live in this run."""
     rc = replayed_counters(kernel_name, shape, dtype)
     if not rc:
-        roofline["traffic_note"] = (f"no committed PMC file names kernel {kernel_name!r} at {list(shape)}: traffic and MFMA "
-                                    "utilisation not reported rather than replayed from another kernel")
+        roofline["traffic_note"] = "no committed PMC file names this kernel at this shape: not replayed from another kernel"
         return roofline
     if roofline.get("bound") != "mfma":            # a VALU kernel has no MFMA utilisation to report
         for key in ("mfma_util_pct", "mfma_util_source"):
@@ -183,10 +247,7 @@ def attach_replayed(roofline, kernel_name, shape, dtype=None):
     roofline.update(rc)
     if "traffic" in rc:
         roofline["achieved_fabric_GBps"] = round(rc["traffic"] / (1e-3 * roofline["avg_launch_ms"]) / 1e9, 1)
-    roofline["traffic_note"] = ("traffic (L2 <-> fabric bytes per launch, Infinity-Cache hits included), mfma_util_pct, "
-                                "profiled_clock_GHz and l2_hit_rate are REPLAYED from the committed rocprofv3 PMC files "
-                                "named in *_source, which profiled this same kernel on this shape; they are not measured "
-                                "in this run")
+    roofline["counters_measured_in_this_run"] = False      # replayed: see the top-level "notes"
     return roofline
 
 
@@ -233,9 +294,7 @@ def roofline_obj(dtype, roof, peak, rows, k, m, launch_ms):
             "frac": round(achieved / peak, 4), "traffic": None,
             "algorithmic_flops_per_launch": 2.0 * rows * k * m,
             "algorithmic_bytes_per_launch": float((rows * k + k * m + rows * m) * es),
-            "avg_launch_ms": round(1e3 * avg_s, 4),
-            **({"power_ceiling": POWER_CEILING[dtype]} if dtype in POWER_CEILING else {}),
-            **({"mfma_sustained": MFMA_SUSTAINED[dtype]} if dtype in MFMA_SUSTAINED and roof == "mfma" else {})}
+            "avg_launch_ms": round(1e3 * avg_s, 4)}   # (what the part sustains from registers alone: top-level "context")
 
 
 def extra_workloads(g, torch, dev, local_rank, steps=5):
@@ -259,32 +318,44 @@ def extra_workloads(g, torch, dev, local_rank, steps=5):
             value = 1e-9 * 2.0 * rows * k * m * steps / elapsed
             entry = {"workload": f"{dtype} {rows}x{k}x{m} ({map_op},{reduce_op}) on 1 MI355X"
                                  + ("; BASELINE configs[4]'s job without the split" if rows_override else "")
-                                 + ("; A stored K x N (MM_TRANSPOSED_A): transposition pre-pass + row-major kernel, both inside the timed step" if kxn else ""),
+                                 + ("; A stored K x N (MM_TRANSPOSED_A): pre-pass + kernel both timed" if kxn else ""),
                      "kernel": g.kernel_name(g.make_config(dtype, map_op, reduce_op, path, kxn), rows, k, m),
                      "dtype": DTYPE_TAG[dtype], "value": round(value, 1), "unit": "GOp/s", "steps": steps, "warmup": 2,
                      "ms_per_step": round(1e3 * elapsed / steps, 4),
                      "roofline": roofline_obj(dtype, roof, peak, rows, k, m, launch_ms)}
-            if kxn:
-                entry["roofline"]["traffic_note"] = "two kernels per step (transposition pre-pass + product): no single kernel's counters apply"
-            else:
+            entry["key"] = key
+            for drop in ("algorithmic_flops_per_launch", "algorithmic_bytes_per_launch"):   # derivable from the shape; the headline keeps them
+                entry["roofline"].pop(drop, None)
+            if not kxn:   # (two kernels per step there: no single kernel's counters apply)
                 attach_replayed(entry["roofline"], entry["kernel"], (rows, k, m), dtype)
-            if key in VALU_SUSTAINED:
-                entry["roofline"]["valu_sustained"] = VALU_SUSTAINED[key]
             if key == "float_split":
-                entry["workload"] += "; MM_PATH_SPLIT (opt-in), split + re-tile pre-pass inside the timed step"
-                entry["dtype"] = "f32 in/out; operands as 3 bf16 planes, 6 bf16 MFMA products per pair, f32 accumulate"
-                entry["roofline"].pop("mfma_sustained", None)   # that figure is the fp32 MFMA's; this kernel runs on the bf16 one
-                entry["roofline"]["power_ceiling"] = {"register_only_bf16_mfma_on_random_operands_TOps_div_6": round(SPLIT_BF16_REGISTER_ONLY_TOPS / 6.0, 1),
-                                                      "instruction": "v_mfma_f32_32x32x16_bf16", "source": POWER_CEILING["half"]["source"]}
-                entry["roofline"]["peak_note"] = ("bf16 dense MFMA peak 2500 TFLOP/s / 6 MFMAs per fp32 multiply-add block; "
-                                                  "against the fp32 MFMA peak (157.3) the same number is "
-                                                  f"{round(entry['roofline']['achieved'] / 157.3, 3)}")
+                entry["workload"] += "; MM_PATH_SPLIT (opt-in), pre-pass timed"
+                entry["dtype"] = "f32 in/out; 3 bf16 planes, 6 bf16 MFMAs per pair, f32 accumulate"
+                entry["roofline"]["frac_of_fp32_mfma_peak"] = round(entry["roofline"]["achieved"] / 157.3, 3)
             out.append(entry)
         except Exception as exc:  # an extra must never take the headline line down with it
             out.append({"workload": key, "error": repr(exc)})
         a = b = c = None
         torch.cuda.empty_cache()
     return out
+
+
+def baseline_summary(out):
+    """BASELINE.json's configs, one compact entry each: value (GOp/s), ms per step, fraction of the roof, kernel.  Well under
+    1 KB, so that it survives in the tail of the line that the driver's record keeps."""
+    def brief(value, ms, rl, kernel):
+        return {"value": value, "ms": round(ms, 3), "frac": rl.get("frac"), "kernel": kernel}
+    summary = {"unit": "GOp/s", "C2_float_16384": brief(out["value"], out["ms_per_step"], out["roofline"], out["config"]["kernel"])}
+    names = {"half": "C3_half_32768", "double": "C4_double_16384", "minplus": "C5b_minplus_8192", "float": "C5a_float_65536_rows_1gpu"}
+    for w in out.get("workloads", []):
+        if w.get("key") in names and "error" not in w:
+            summary[names[w["key"]]] = brief(w["value"], w["ms_per_step"], w["roofline"], w["kernel"])
+        elif w.get("workload") in names:          # an extra that failed is listed by its key
+            summary[names[w["workload"]]] = {"error": str(w.get("error"))[:60]}
+    cb = out.get("cpu_baseline")
+    if cb:
+        summary["C1_float_1024_ref_cpu_sim"] = {"value": cb.get("value"), "threads": cb.get("cores"), "host_cores": cb.get("host_cores")}
+    return summary
 
 
 def self_launch(gpus):
@@ -482,6 +553,27 @@ def main():
                                                  "strong-scaling factor at G = that line's value / this value"}
         if world == 1 and not args.no_cpu_baseline and headline:
             out["cpu_baseline"] = cpu_baseline()
+        if world == 1 and headline and not args.no_extra:
+            live = live_counters(out["config"]["kernel"], (rows, k, m), rl["avg_launch_ms"])
+            if live:
+                for stale in ("traffic_source", "mfma_util_source", "l2_hit_rate", "profiled_clock_GHz"):
+                    rl.pop(stale, None)
+                rl.update(live)
+        if world == 1 and headline:
+            out["notes"] = {
+                "counters": "roofline objects with counters_measured_in_this_run = true carry rocprofv3 PMC figures collected by this run "
+                            "(counters_how); with false, traffic (L2 <-> fabric bytes per launch, Infinity-Cache hits included), mfma_util_pct, "
+                            "profiled_clock_GHz and l2_hit_rate are REPLAYED from the committed PMC files named in *_source, which profiled the "
+                            "same kernel on the same shape on an earlier box",
+                "peaks": "MI355X_MICROARCH.md dense MFMA peaks (fp32 157.3, fp16 2500, i8 5000 T/s; fp64 78.6 datasheet); min-plus: SURVEY 8(d) "
+                         "VALU ceiling 78.6 T lane-ops/s (fp64: 39.3); float_split: bf16 peak / 6 MFMAs per fp32 multiply-add block"}
+            out["context"] = {"what_the_part_sustains_from_registers_alone": {
+                "float": MFMA_SUSTAINED["float"], "double": MFMA_SUSTAINED["double"], "half": POWER_CEILING["half"], "uint8_t": POWER_CEILING["uint8_t"],
+                "float_split": {"register_only_bf16_mfma_on_random_operands_TOps_div_6": round(SPLIT_BF16_REGISTER_ONLY_TOPS / 6.0, 1),
+                                "instruction": "v_mfma_f32_32x32x16_bf16", "source": POWER_CEILING["half"]["source"]},
+                "minplus_f64": VALU_SUSTAINED["minplus_f64"]}}
+            # LAST key on purpose: the driver's record keeps the tail of this line -- the BASELINE configs, one short entry each
+            out["baseline_summary"] = baseline_summary(out)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -908,6 +908,13 @@ static int launch_tile(hipStream_t s, const Problem &p, Kern kern, unsigned bm, 
   return (int)hipGetLastError();
 }
 
+// A K x N A served where it lies (no workspace): the ping-pong K x N kernel where its shape rules allow, else slab64's
+static int launch_kxn_in_place(hipStream_t s, const Problem &p, unsigned long long (&cfg)[K_NONE]) {
+  if (tuning(TUNE_F16_VARIANT) != 0 && ppk32_serves(p))
+    return launch_tile(s, p, mfma_f16_pp_kernel<true>, 256, 256, GeoPP::THREADS, GeoPP::LDS_BYTES, cfg[K_PPK32_AT]);
+  return launch_tile(s, p, mfma_f16_kernel<GeoH, true>, GeoH::BM, GeoH::BN, GeoH::THREADS, GeoH::LDS_BYTES, cfg[K_SLAB64_AT]);
+}
+
 int launch_mfma_f16(hipStream_t s, const Problem &p) {
   static unsigned long long cfg[K_NONE] = {};
   if (transposes_first(p)) {
@@ -917,7 +924,12 @@ int launch_mfma_f16(hipStream_t s, const Problem &p) {
     hipMemPool_t pool = nullptr;
     if (int rc = workspace_pool(dev, &pool)) return rc;
     void *an = nullptr;
-    if ((e = hipMallocFromPoolAsync(&an, (size_t)p.n * p.k * 2, pool, s)) != hipSuccess) return (int)e;
+    if ((e = hipMallocFromPoolAsync(&an, (size_t)p.n * p.k * 2, pool, s)) != hipSuccess) {
+      // no room for the N x K copy (up to 4 GiB next to a nearly full device): not an error -- the K x N kernels serve the
+      // call without extra memory, as they did before the pre-pass existed; same contract, ~2-3 % slower
+      (void)hipGetLastError();
+      return launch_kxn_in_place(s, p, cfg);
+    }
     int rc = launch_transpose_kxn(s, p.a, an, p.k, p.n, 2);
     if (rc == 0) {
       Problem q = p;

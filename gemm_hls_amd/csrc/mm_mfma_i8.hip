@@ -803,6 +803,13 @@ static int launch_tile(hipStream_t s, const Problem &p, Kern kern, unsigned thre
   return (int)hipGetLastError();
 }
 
+// A K x N A served where it lies (no workspace): the ping-pong K x N kernel where its shape rules allow, else slab128's
+static int launch_kxn_in_place(hipStream_t s, const Problem &p, unsigned long long (&cfg)[K_NONE]) {
+  if (tuning(TUNE_I8_VARIANT) != 0 && ppk64_serves(p))
+    return launch_tile(s, p, mfma_i8_pp_kernel<true>, GeoI8PP::THREADS, GeoI8PP::LDS_BYTES, cfg[K_PPK64_AT]);
+  return launch_tile(s, p, mfma_i8_kernel<GeoI8, true>, GeoI8::THREADS, GeoI8::LDS_BYTES, cfg[K_SLAB128_AT]);
+}
+
 int launch_mfma_i8(hipStream_t s, const Problem &p) {
   static unsigned long long cfg[K_NONE] = {};
   if (transposes_first(p)) {
@@ -812,7 +819,12 @@ int launch_mfma_i8(hipStream_t s, const Problem &p) {
     hipMemPool_t pool = nullptr;
     if (int rc = workspace_pool(dev, &pool)) return rc;
     void *an = nullptr;
-    if ((e = hipMallocFromPoolAsync(&an, (size_t)p.n * p.k, pool, s)) != hipSuccess) return (int)e;
+    if ((e = hipMallocFromPoolAsync(&an, (size_t)p.n * p.k, pool, s)) != hipSuccess) {
+      // no room for the N x K copy (up to 4 GiB next to a nearly full device): not an error -- the K x N kernels serve the
+      // call without extra memory, as they did before the pre-pass existed; same contract, ~2-3 % slower
+      (void)hipGetLastError();
+      return launch_kxn_in_place(s, p, cfg);
+    }
     int rc = launch_transpose_kxn(s, p.a, an, p.k, p.n, 1);
     if (rc == 0) {
       Problem q = p;

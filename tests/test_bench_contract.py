@@ -48,9 +48,9 @@ def test_replayed_counters_only_come_from_files_that_name_the_dispatched_kernel(
     assert rc["mfma_util_pct"] == 97.8 and rc["mfma_util_source"] == "profiles/r03_pmc.json"
     assert b.replayed_counters("mfma_f32_128x128x32_w4x2_flush4096", (16384, 16384, 16384)) == {}
     rl = b.attach_replayed({"avg_launch_ms": 58.0, "traffic": None}, "some_other_kernel", (16384, 16384, 16384))
-    assert rl["traffic"] is None and "not reported" in rl["traffic_note"]
+    assert rl["traffic"] is None and "not replayed from another kernel" in rl["traffic_note"]
     rl = b.attach_replayed({"avg_launch_ms": 58.0, "traffic": None}, "mfma_f32_128x256x16_w4x2_flush4096", (16384,) * 3)
-    assert abs(rl["achieved_fabric_GBps"] - 51.8e9 / 58.0e-3 / 1e9) < 0.1 and "REPLAYED" in rl["traffic_note"]
+    assert abs(rl["achieved_fabric_GBps"] - 51.8e9 / 58.0e-3 / 1e9) < 0.1 and rl["counters_measured_in_this_run"] is False
 
 
 def test_replayed_counters_of_the_generic_semiring_kernel_are_matched_by_data_type(tmp_path, monkeypatch):
@@ -139,3 +139,29 @@ def test_plain_launch_reaches_the_ranks_without_a_gpu():
     if torch.cuda.is_available():
         pytest.skip("GPU box: covered by tests/test_gpu_capi.py")
     assert r.returncode != 0 and "needs an MI355X" in r.stderr and "torch.distributed.run" in r.stderr
+
+
+def test_baseline_summary_is_compact_and_last():
+    """VERDICT r4 missing 4: the driver's record keeps the TAIL of the line; the BASELINE configs must be there, short."""
+    b = _bench()
+    rl = {"frac": 0.95}
+    out = {"value": 150000.0, "ms_per_step": 58.5, "roofline": rl, "config": {"kernel": "mfma_f32_256x256x16_w8_flush4096"},
+           "workloads": [{"key": k, "workload": k, "value": 1.0e6, "ms_per_step": 47.123456, "roofline": {"frac": 0.6}, "kernel": "mfma_f16_256x256_pingpong_16x16x32"}
+                         for k in ("half", "double", "minplus", "minplus_f64", "uint8", "float", "float_split", "half_kxn")] + [{"workload": "uint8_kxn", "error": "x" * 500}],
+           "cpu_baseline": {"value": 0.28, "unit": "GFLOP/s", "cores": 39, "host_cores": 256, "seconds": 7.6}}
+    summary = b.baseline_summary(out)
+    assert {"C2_float_16384", "C3_half_32768", "C4_double_16384", "C5b_minplus_8192", "C5a_float_65536_rows_1gpu",
+            "C1_float_1024_ref_cpu_sim"} == set(summary) - {"unit"}
+    assert summary["C3_half_32768"]["frac"] == 0.6 and summary["C2_float_16384"]["frac"] == 0.95
+    assert len(json.dumps(summary)) < 900
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert src.index('out["baseline_summary"] = baseline_summary(out)') > src.index('out["context"]') > src.index('out["cpu_baseline"] = cpu_baseline()')
+
+
+def test_live_counters_are_skipped_quietly_where_they_cannot_run(monkeypatch):
+    b = _bench()
+    monkeypatch.setenv("MM_BENCH_NO_PMC", "1")
+    assert b.live_counters(b.LIVE_KERNEL, (16384,) * 3, 58.0) is None
+    monkeypatch.delenv("MM_BENCH_NO_PMC")
+    assert b.live_counters("mfma_f32_128x256x16_w4x2_flush4096", (16384,) * 3, 58.0) is None      # not the kernel the passes pin
+    assert b.live_counters(b.LIVE_KERNEL, (8192,) * 3, 58.0) is None

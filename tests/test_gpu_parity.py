@@ -802,13 +802,10 @@ def test_multi_device_api_contract():
         assert np.array_equal(c, want) and t > 0
     with pytest.raises(g.MMError, match="device_count"):
         g.matmul_host(a, b, "int", devices=have + 1)   # never silently uses fewer devices
+    # a K x N A (MM_TRANSPOSED_A) is served too since round 5 (column slabs; G > 1: tests/test_gpu_multi_device.py)
     at = np.ascontiguousarray(a.T)
-    with pytest.raises(g.MMError):
-        cfg = g.make_config("int", transposed_a=True)
-        import ctypes
-        c = np.empty((130, 96), np.int32)
-        g._check(g.lib().mm_gemm_multi_device(1, ctypes.byref(cfg), at.ctypes.data, b.ctypes.data, c.ctypes.data,
-                                               130, 64, 96, None))
+    ct, _ = g.matmul_host(at, b, "int", devices=1, transposed_a=True)
+    assert np.array_equal(ct, want)
 
 
 def test_reference_entry_point_symbol():
