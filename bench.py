@@ -216,7 +216,7 @@ def live_counters(kernel_name, shape, avg_launch_ms, timeout=240):
         busy, dur_ns, _ = one_pass(["SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"], "mfma")
         traffic = 2.0 * fetch["FETCH_SIZE"] * 1024.0 + write["WRITE_SIZE"] * 1024.0
         gui = busy["GRBM_GUI_ACTIVE"] / 8.0          # rocprofv3 sums the 8 XCDs
-        out = {"traffic": traffic, "fetch_bytes_corrected": 2.0 * fetch["FETCH_SIZE"] * 1024.0, "write_bytes": write["WRITE_SIZE"] * 1024.0,
+        out = {"traffic": int(traffic), "fetch_bytes_corrected": int(2.0 * fetch["FETCH_SIZE"] * 1024.0), "write_bytes": int(write["WRITE_SIZE"] * 1024.0),
                "mfma_util_pct": round(100.0 * busy["SQ_VALU_MFMA_BUSY_CYCLES"] / (gui * 1024), 2),
                "achieved_fabric_GBps": round(traffic / (1e-3 * avg_launch_ms) / 1e9, 1),
                "counters_measured_in_this_run": True, "launches_profiled_per_pass": launches,
@@ -300,10 +300,10 @@ def roofline_obj(dtype, roof, peak, rows, k, m, launch_ms):
 def extra_workloads(g, torch, dev, local_rank, steps=5):
     """The other single-GPU BASELINE configs, a few steps each, in the same process."""
     out = []
-    # half_kxn / uint8_kxn (round 4, for one round): the same problems with A handed over K x N (MM_TRANSPOSED_A,
-    # kernel/Memory.cpp:205-261) -- a transposition pre-pass inside the timed step, then the row-major default
+    # (MM_EXTRA_KXN=1 adds half_kxn / uint8_kxn, round 4's one-round extras: the same problems with A handed over K x N,
+    # MM_TRANSPOSED_A, kernel/Memory.cpp:205-261 -- a transposition pre-pass inside the timed step, then the row-major default)
     jobs = [("half", None), ("double", None), ("minplus", None), ("minplus_f64", None), ("uint8", None), ("float", C5A_ROWS),
-            ("float_split", None), ("half_kxn", None), ("uint8_kxn", None)]
+            ("float_split", None)] + ([("half_kxn", None), ("uint8_kxn", None)] if os.environ.get("MM_EXTRA_KXN") == "1" else [])
     for key, rows_override in jobs:
         kxn = key.endswith("_kxn")
         dtype, map_op, reduce_op, size, roof, peak = WORKLOADS[key[:-4] if kxn else key]

@@ -47,7 +47,7 @@
 // kernel, same per-element arithmetic), split-K with an ordered reduce kernel (few tiles, long K), stream-K in teams with
 // an in-launch ordered hand-over (between whole rounds), and a transposition pre-pass for a K x N A outside whole rounds
 // of the K x N kernel.  Every one of them is deterministic; the whole-tile forms are bit-identical to one another.
-// The schedules, ring depths and ablations this kernel went through live in
+// The schedules, ring depths and ablations this kernel went through (HISTORY.md 3.1) live in
 // tools/lab/lab_mfma_f32.hip and are built into tools/lab/libmm_gemm_amd_lab.so, not into the product.
 //
 // Edges: N arbitrary (row indices clamped for loads, stores predicated); M % 4 == 0 (column

@@ -26,7 +26,7 @@
 //     reads and 6 DMA pieces.  Shipped schedule: ping-pong -- a load segment and a compute segment per
 //     stage, the two wavefronts of a SIMD one segment apart (pp_stage below).  Kept as variants: one
 //     barrier per stage with double-buffered fragment registers, reads ahead of / interleaved with
-//     the MFMA groups (stage below) -- the steps this kernel went through.
+//     the MFMA groups (stage below) -- the steps this kernel went through (HISTORY.md 3.3).
 //
 // The workspace (6 bytes per element of A and B, padded to whole blocks/slabs) is allocated
 // stream-ordered (hipMallocAsync / hipFreeAsync on the launch stream): no hidden global state, safe

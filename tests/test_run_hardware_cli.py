@@ -307,7 +307,7 @@ def test_static_size_build_runs_on_gpu(args):
 def test_optimal_tile_size_tool_reproduces_the_shipped_tiles():
     """tools/optimal_tile_size.py = the reference's scripts/optimal_memory_tile_size.py with a CU's register file and
     LDS as the budgets: under the power-of-two restriction it lands on the tiles the kernels ship with, and without
-    it on the 320 x 256 tile DESIGN.md lists as open."""
+    it on the 320 x 256 tile HISTORY.md lists as open."""
     import sys
     tool = os.path.join(ROOT, "tools", "optimal_tile_size.py")
 
