@@ -412,7 +412,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    # MM_BENCH_FORCE_DIST=1 (tests): form the control plane even for one rank, so that the RCCL init / all-reduce / barrier
+    # sequence the N > 1 runs depend on is exercised on a 1-GPU box (tests/test_gpu_multi_device.py)
+    use_dist = world > 1 or (os.environ.get("MM_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
+    if use_dist:
         import torch.distributed as dist
         # control plane only: barrier + max(t).  The data path has no collective.
         if backend == "nccl":
@@ -431,13 +434,13 @@ def main():
             dist.init_process_group(backend=backend)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     ctl_dev = dev if backend == "nccl" else "cpu"
 
     def max_over_ranks(x):
-        if world == 1:
+        if not use_dist:
             return x
         t = torch.tensor([x], dtype=torch.float64, device=ctl_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -445,7 +448,7 @@ def main():
 
     def rows_of_every_rank(rows):
         """What every rank actually owns, as the formed communicator reports it (one slot per rank, summed)."""
-        if world == 1:
+        if not use_dist:
             return [rows]
         t = torch.zeros(world, dtype=torch.float64, device=ctl_dev)
         t[rank] = rows
@@ -453,7 +456,7 @@ def main():
         return [int(x) for x in t.tolist()]
 
     ranks_seen = 1
-    if world > 1:
+    if use_dist:
         one = torch.ones(1, dtype=torch.float64, device=ctl_dev)
         dist.all_reduce(one)                      # every rank of the communicator contributes 1
         ranks_seen = int(one.item())
@@ -530,7 +533,7 @@ def main():
                        "kernel": g.kernel_name(g.make_config(dtype, map_op, reduce_op, PATHS.get(args.workload, 0)), rows, k, m),
                        "rows_total": n_total, "rows_per_gpu": rows_all if world > 1 else rows},
             # the data path has no collective; this is the barrier / max-over-ranks plane only
-            "control_plane": {"backend": ("rccl (torch.distributed 'nccl')" if backend == "nccl" else backend) if world > 1 else "none",
+            "control_plane": {"backend": ("rccl (torch.distributed 'nccl')" if backend == "nccl" else backend) if use_dist else "none",
                               "ranks_seen": ranks_seen, "devices_visible": torch.cuda.device_count()},
             "roofline": rl,
         }
@@ -575,7 +578,7 @@ def main():
             # LAST key on purpose: the driver's record keeps the tail of this line -- the BASELINE configs, one short entry each
             out["baseline_summary"] = baseline_summary(out)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

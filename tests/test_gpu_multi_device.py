@@ -186,3 +186,27 @@ def test_multi_device_bench_eight_ranks_on_one_device_dry_run():
     assert out["weak_scaling"]["value"] > 0 and "16384 rows per GPU" in out["weak_scaling"]["workload"]
     # eight ranks time-share ONE device here: the whole job cannot run faster than one device's roof
     assert out["value"] < 157.3e3 * 1.02
+
+
+def test_multi_device_bench_control_plane_on_rccl_with_one_rank():
+    """The control plane of the N > 1 runs is RCCL (torch.distributed 'nccl'): init with device_id, an all-reduce that builds
+    the communicator outside the timed region, barrier, MAX over ranks, the per-rank row census, destroy.  Two ranks cannot
+    share one device under RCCL, so the 8-rank dry run above uses gloo; this runs the SAME code path on the real backend
+    with the one rank a 1-GPU box allows, under the launcher the driver uses."""
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "MM_BENCH_BACKEND")}
+    env.update(MM_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--size", "4096",
+           "--no-extra", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 1 and out["value"] > 0 and out["control_plane"]["ranks_seen"] == 1
+    if not out["control_plane"]["backend"].startswith("rccl"):
+        # bench.py falls back to gloo for barrier / max when RCCL cannot form (by design: the data path has no collective)
+        pytest.skip("RCCL control plane did not form on this box; bench.py fell back to " + out["control_plane"]["backend"] + ": "
+                    + r.stderr[-400:])
