@@ -169,20 +169,29 @@ def replayed_counters(kernel_name, shape, dtype=None):
     return out
 
 
-LIVE_KERNEL = "mfma_f32_256x256x16_w8_flush4096"   # f32_variant 8: what the PMC child passes pin and what the headline must have run
+# Counters MEASURED IN THIS RUN.  key -> (mm_kernel_name the passes must be profiling, tools/sweep.py arguments, substring of the
+# kernel's symbol in rocprofv3's CSVs, has an MFMA pass).  The passes run tools/sweep.py -- the same C-ABI launch on device-filled operands -- as children.
+LIVE = {
+    "float": ("mfma_f32_256x256x16_w8_flush4096", ["f32", "--variants", "8"], "mfma_f32_kernel", True),
+    "half": ("mfma_f16_256x256_pingpong_16x16x32", ["f16"], "mfma_f16_", True),
+    "double": ("mfma_f64_256x128x16_w8", ["f64"], "mfma_f64_kernel", True),
+    "minplus": ("valu_tile", ["minplus"], "valu_tile_", False),
+}
+LIVE_KERNEL = LIVE["float"][0]
 
 
-def live_counters(kernel_name, shape, avg_launch_ms, timeout=240):
-    """Counters of the headline kernel MEASURED IN THIS RUN: three rocprofv3 child passes of
-    tools/sweep.py on the same shape -- FETCH_SIZE, WRITE_SIZE (separate --pmc passes, gfx950 correction: fetch doubled,
-    MI355X_MICROARCH.md HBM section) and SQ_VALU_MFMA_BUSY_CYCLES + GRBM_GUI_ACTIVE -- each with --kernel-trace only.  Run
-    after every timed leg (the passes serialise and slow the kernel).  Returns None when rocprofv3 is absent, the kernel is
-    not the one the passes pin, or a pass fails: the caller then falls back to the replayed figures."""
+def live_counters(kernel_name, shape, avg_launch_ms, key="float", timeout=240):
+    """rocprofv3 child passes on the same shape after the timed legs (they serialise and slow the kernel): FETCH_SIZE, WRITE_SIZE in
+    separate --pmc passes (gfx950 correction: fetch doubled, MI355X_MICROARCH.md HBM section) and, for the matrix-core kernels,
+    SQ_VALU_MFMA_BUSY_CYCLES + GRBM_GUI_ACTIVE -- each with --kernel-trace only.  Returns None when rocprofv3 is absent, the kernel
+    is not the one the passes profile, or a pass fails: the caller then keeps the replayed figures."""
     import shutil
     import tempfile
-    if os.environ.get("MM_BENCH_NO_PMC") or shutil.which("rocprofv3") is None or kernel_name != LIVE_KERNEL or list(shape) != [SIZE] * 3:
+    want, sweep_args, symbol, has_mfma = LIVE[key]
+    size = shape[0]
+    if (os.environ.get("MM_BENCH_NO_PMC") or shutil.which("rocprofv3") is None or kernel_name != want or list(shape) != [size] * 3
+            or size != WORKLOADS[key][3]):
         return None
-    sys.path.insert(0, os.path.join(ROOT, "tools"))
     workdir = tempfile.mkdtemp(prefix="mm_bench_pmc_", dir="/tmp")
     try:
         import csv
@@ -193,18 +202,18 @@ def live_counters(kernel_name, shape, avg_launch_ms, timeout=240):
             d = os.path.join(workdir, tag)
             os.makedirs(d, exist_ok=True)
             cmd = ["rocprofv3", "--pmc", *counters, "--kernel-trace", "-d", d, "-o", "pmc", "--output-format", "csv", "--",
-                   sys.executable, os.path.join(ROOT, "tools", "sweep.py"), "f32", "--sizes", str(SIZE), "--reps", "2", "--variants", "8"]
+                   sys.executable, os.path.join(ROOT, "tools", "sweep.py"), sweep_args[0], "--sizes", str(size), "--reps", "2", *sweep_args[1:]]
             r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=timeout)
             if r.returncode != 0:
                 raise RuntimeError(f"rocprofv3 {tag}: rc {r.returncode}: {(r.stderr or r.stdout)[-300:]}")
             vals, durs = {}, []
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 for row in csv.DictReader(open(f)):
-                    if "mfma_f32_kernel" in row.get("Kernel_Name", ""):
+                    if symbol in row.get("Kernel_Name", ""):
                         vals.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
             for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
                 for row in csv.DictReader(open(f)):
-                    if "mfma_f32_kernel" in row.get("Kernel_Name", ""):
+                    if symbol in row.get("Kernel_Name", ""):
                         durs.append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
             if not vals:
                 raise RuntimeError(f"rocprofv3 {tag}: no counter rows for the kernel")
@@ -213,22 +222,21 @@ def live_counters(kernel_name, shape, avg_launch_ms, timeout=240):
         t0 = time.perf_counter()
         fetch, _, launches = one_pass(["FETCH_SIZE"], "fetch")
         write, _, _ = one_pass(["WRITE_SIZE"], "write")
-        busy, dur_ns, _ = one_pass(["SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"], "mfma")
         traffic = 2.0 * fetch["FETCH_SIZE"] * 1024.0 + write["WRITE_SIZE"] * 1024.0
-        gui = busy["GRBM_GUI_ACTIVE"] / 8.0          # rocprofv3 sums the 8 XCDs
         out = {"traffic": int(traffic), "fetch_bytes_corrected": int(2.0 * fetch["FETCH_SIZE"] * 1024.0), "write_bytes": int(write["WRITE_SIZE"] * 1024.0),
-               "mfma_util_pct": round(100.0 * busy["SQ_VALU_MFMA_BUSY_CYCLES"] / (gui * 1024), 2),
                "achieved_fabric_GBps": round(traffic / (1e-3 * avg_launch_ms) / 1e9, 1),
-               "counters_measured_in_this_run": True, "launches_profiled_per_pass": launches,
-               "counter_passes_s": round(time.perf_counter() - t0, 1),
-               "counters_how": "3 rocprofv3 child passes (--pmc X --kernel-trace) of tools/sweep.py f32 16384 on this box after the timed legs: "
-                               "FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, KiB -> bytes per launch; MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs)"}
-        if dur_ns:
-            out["profiled_clock_GHz"] = round(gui / dur_ns, 3)
-            out["profiled_launch_ms"] = round(dur_ns * 1e-6, 3)
+               "counters_measured_in_this_run": True, "launches_profiled_per_pass": launches}
+        if has_mfma:
+            busy, dur_ns, _ = one_pass(["SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"], "mfma")
+            gui = busy["GRBM_GUI_ACTIVE"] / 8.0          # rocprofv3 sums the 8 XCDs
+            out["mfma_util_pct"] = round(100.0 * busy["SQ_VALU_MFMA_BUSY_CYCLES"] / (gui * 1024), 2)
+            if dur_ns:
+                out["profiled_clock_GHz"] = round(gui / dur_ns, 3)
+                out["profiled_launch_ms"] = round(dur_ns * 1e-6, 3)
+        out["counter_passes_s"] = round(time.perf_counter() - t0, 1)
         return out
-    except Exception as exc:   # a counter pass must never take the headline line down with it
-        sys.stderr.write(f"[bench] live counters unavailable: {exc!r}\n")
+    except Exception as exc:   # a counter pass must never take the line down with it
+        sys.stderr.write(f"[bench] live counters for {key} unavailable: {exc!r}\n")
         return None
     finally:
         shutil.rmtree(workdir, ignore_errors=True)
@@ -557,15 +565,21 @@ def main():
         if world == 1 and not args.no_cpu_baseline and headline:
             out["cpu_baseline"] = cpu_baseline()
         if world == 1 and headline and not args.no_extra:
-            live = live_counters(out["config"]["kernel"], (rows, k, m), rl["avg_launch_ms"])
-            if live:
-                for stale in ("traffic_source", "mfma_util_source", "l2_hit_rate", "profiled_clock_GHz"):
-                    rl.pop(stale, None)
-                rl.update(live)
+            # counters measured in this run, after every timed leg: the headline kernel and BASELINE's C3 / C4 / C5b kernels
+            targets = [("float", rl, out["config"]["kernel"], (rows, k, m))]
+            targets += [(w["key"], w["roofline"], w["kernel"], (WORKLOADS[w["key"]][3],) * 3) for w in out["workloads"]
+                        if w.get("key") in ("half", "double", "minplus") and "roofline" in w]
+            for key, obj, kernel, shape in targets:
+                live = live_counters(kernel, shape, obj["avg_launch_ms"], key)
+                if live:
+                    for stale in ("traffic_source", "mfma_util_source", "l2_hit_rate", "profiled_clock_GHz", "mfma_util_pct"):
+                        obj.pop(stale, None)
+                    obj.update(live)
         if world == 1 and headline:
             out["notes"] = {
-                "counters": "roofline objects with counters_measured_in_this_run = true carry rocprofv3 PMC figures collected by this run "
-                            "(counters_how); with false, traffic (L2 <-> fabric bytes per launch, Infinity-Cache hits included), mfma_util_pct, "
+                "counters": "roofline objects with counters_measured_in_this_run = true carry rocprofv3 PMC figures collected by this run: child passes "
+                            "(--pmc X --kernel-trace) of tools/sweep.py on the same shape after the timed legs; traffic = FETCH_SIZE x2 (gfx950 correction) + "
+                            "WRITE_SIZE, KiB -> bytes per launch; MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs).  With false, traffic (L2 <-> fabric bytes per launch, Infinity-Cache hits included), mfma_util_pct, "
                             "profiled_clock_GHz and l2_hit_rate are REPLAYED from the committed PMC files named in *_source, which profiled the "
                             "same kernel on the same shape on an earlier box",
                 "peaks": "MI355X_MICROARCH.md dense MFMA peaks (fp32 157.3, fp16 2500, i8 5000 T/s; fp64 78.6 datasheet); min-plus: SURVEY 8(d) "
