@@ -111,3 +111,30 @@ def test_full_build_description_compiles_every_kernel_source():
             if src.endswith(".hip"):
                 assert src in rules, src
         assert "--offload-arch=gfx950" in rules and "-ffp-contract=off" in rules and "libmm_gemm_amd.so" in rules
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/host"), reason="needs the reference checkout (not present on the GPU box)")
+def test_reference_dir_option_builds_the_references_own_hosts_unmodified(tmp_path):
+    """-DMM_REFERENCE_DIR=<gemm_hls checkout>: the reference's host/RunHardware.cpp, test/TestSimulation.cpp and
+    src/PrintSpecifications.cpp are compiled from where they lie against include/compat, with Config.h configured from the
+    reference's own include/Config.h.in by CMake's configure_file (as the reference's CMakeLists.txt:136 does)."""
+    build, r = _configure(tmp_path, "-DMM_REFERENCE_DIR=/root/reference")
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "Reference hosts:" in r.stdout
+    _build(build)
+    cfg = open(build / "reference" / "Config.h").read()
+    assert "using Data_t = float;" in cfg and "hlslib::op::Multiply<Data_t>" in cfg and "${" not in cfg
+    u = subprocess.run([str(build / "RunHardware_reference.exe")], capture_output=True, text=True)
+    assert u.returncode == 1 and "Usage: ./RunHardware.exe N K M" in u.stderr
+    u = subprocess.run([str(build / "RunHardware_reference.exe"), "513", "520", "528"], capture_output=True, text=True)
+    assert u.returncode == 1 and "K (520) must be divisable by the memory width in K (16)." in u.stderr
+    p = subprocess.run([str(build / "PrintSpecifications_reference"), "16384", "16384", "16384"], capture_output=True, text=True)
+    assert p.returncode == 0 and "Number of operations: 8796093022208" in p.stdout
+    assert (build / "TestSimulation_reference").exists()
+    t = subprocess.run(["ctest", "-N"], cwd=build, capture_output=True, text=True)
+    assert "ReferenceRunHardwareVerify" in t.stdout and "ReferenceTestSimulation" in t.stdout
+    # a half, K x N build of the same sources
+    build2, r = _configure(tmp_path / "h", "-DMM_REFERENCE_DIR=/root/reference", "-DMM_DATA_TYPE=half", "-DMM_TRANSPOSED_A=ON")
+    assert r.returncode == 0, r.stdout + r.stderr
+    _build(build2)
+    assert "using Data_t = half;" in open(build2 / "reference" / "Config.h").read()
