@@ -89,6 +89,7 @@ def test_multi_device_slab_bookkeeping_matches_mm_row_slab(virtual_devices, devi
 @pytest.mark.parametrize("dtype,npdt,shape", [
     ("float", np.float32, (2516, 512, 528)),      # N % 4 == 0: the K x N matrix-core kernels serve the job and every slab
     ("float", np.float32, (2513, 512, 528)),      # N % 4 != 0: the job's family is the generic one -- and so is every slab's
+    ("float", np.float32, (4096, 512, 4096)),     # one device: a whole round of the K x N kernel's tiles; slabs: transposed first, row-major geometry -- same bits
     ("int", np.int32, (1001, 64, 96)),
     ("half", np.float16, (1304, 256, 264)),
     ("double", np.float64, (778, 256, 130)),
