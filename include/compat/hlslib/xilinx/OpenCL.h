@@ -68,6 +68,7 @@ class ConfigurationError : public std::runtime_error {
 
 enum class Access { read, write, readWrite };
 enum class StorageType { DDR, HBM };
+enum class MemoryBank { unspecified, bank0, bank1, bank2, bank3 }; /* hlslib's older bank form; ignored like the (type, index) pair */
 
 /* std::vector allocator with a fixed alignment: include/Utility.h:48, host/RunHardware.cpp:94-97 (4096 bytes). */
 template <typename T, std::size_t alignment>
@@ -282,6 +283,10 @@ class Context {
   }
   template <typename T, Access access>
   Buffer<T, access> MakeBuffer(std::size_t elements) {
+    return Buffer<T, access>(device_, elements);
+  }
+  template <typename T, Access access>
+  Buffer<T, access> MakeBuffer(MemoryBank, std::size_t elements) {
     return Buffer<T, access>(device_, elements);
   }
   template <typename T, Access access, typename Iterator>
