@@ -45,7 +45,7 @@
 // geometries: the three big-tile geometries through one kernel body (tile_body), and around it the launch forms for
 // problems that do not fill whole rounds of tiles -- the 64 x 64 geometry (below a round of 128 x 128 tiles; its own small
 // kernel, same per-element arithmetic), split-K with an ordered reduce kernel (few tiles, long K), stream-K in teams with
-// an in-launch ordered hand-over (between whole rounds), and a transposition pre-pass for a K x N A outside whole rounds
+// a fix-up kernel (between whole rounds; the in-launch hand-over form is opt-in), and a transposition pre-pass for a K x N A outside whole rounds
 // of the K x N kernel.  Every one of them is deterministic; the whole-tile forms are bit-identical to one another.
 // The schedules, ring depths and ablations this kernel went through (HISTORY.md 3.1) live in
 // tools/lab/lab_mfma_f32.hip and are built into tools/lab/libmm_gemm_amd_lab.so, not into the product.
