@@ -428,7 +428,9 @@ def main():
         # control plane only: barrier + max(t).  The data path has no collective.
         if backend == "nccl":
             try:
-                dist.init_process_group(backend="nccl", device_id=dev)
+                import datetime
+                # (a bounded wait: a communicator that cannot form must end in the gloo fall-back below, not in a hung bench)
+                dist.init_process_group(backend="nccl", device_id=dev, timeout=datetime.timedelta(seconds=300))
                 probe = torch.zeros(1, device=dev)
                 dist.all_reduce(probe)            # builds the RCCL communicator now, outside the timed region
                 torch.cuda.synchronize()
