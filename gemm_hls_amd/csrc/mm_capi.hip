@@ -762,9 +762,10 @@ const char *mm_kernel_name(const mm_config_t *cfg, unsigned n, unsigned k, unsig
                                                         "mfma_f32_64x64x32_w4x2_splitk8"};
         return small_split_names[splits];
       }
-      if (splits == 0) return "mfma_f32_128x128x32_w4x2_streamk";            // teams + fix-up kernel: what MM_PATH_AUTO runs
-      if (splits == 9) return "mfma_f32_128x128x32_w4x2_streamk_fixup";      // single ranges + fix-up kernel (cross-check)
-      if (splits == 10) return "mfma_f32_128x128x32_w4x2_streamk_handover";  // opt-in one-kernel form; the bits of `streamk`
+      if (splits == 0) return "mfma_f32_128x128x32_w4x2_streamk";            // teams, the last part to arrive gathers: what MM_PATH_AUTO runs
+      if (splits == 9) return "mfma_f32_128x128x32_w4x2_streamk_fixup";      // single ranges + fix-up kernel (cross-check, its own bits)
+      if (splits == 10) return "mfma_f32_128x128x32_w4x2_streamk_handover";  // opt-in waiting form; the bits of `streamk`
+      if (splits == 11) return "mfma_f32_128x128x32_w4x2_streamk_two_kernels";   // teams + fix-up kernel (cross-check); the bits of `streamk`
       return splits > 1 ? split_names[splits] : mm::mfma_f32_name(v);
     }
     case FAM_MFMA_F64: return mm::mfma_f64_name(p);

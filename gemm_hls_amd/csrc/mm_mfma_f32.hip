@@ -856,15 +856,30 @@ __global__ __launch_bounds__(G::THREADS, G::MIN_WAVES) void mfma_f32_streamk_ker
 // of them and each B slab by sr.  Per lane this is exactly the scheme above with `teams` ranges.  Tiles of a ragged
 // super-tile that fall outside the matrix are skipped by their lane (the same lane in every team, so no flag is missed).
 //
-// HANDOVER = false is the form MM_PATH_AUTO runs: the same teams, ranges and slots, but nobody waits -- the lowest-k part
+// Combine::FixupKernel (f32_splitk 11; round 5's first answer, kept as the cross-check): the same teams, ranges and slots, but nobody waits -- the lowest-k part
 // of a cut tile goes to C, the other parts to their slots (plain stores, no flags), and streamk_teams_fixup_kernel below
 // adds the slots on top of C in the same ascending-k order.  Bit-identical to the hand-over form (the same additions in
 // the same order), residency-independent (no workgroup ever waits for another one), one more small kernel.
-template <typename G, bool HANDOVER>
+//
+// Combine::LastArriver (round 5, what MM_PATH_AUTO runs): ONE kernel, and still nobody waits.  Every part of a cut tile --
+// the lowest-k one included -- goes to a scratch slot (agent-scope stores) and raises its flag; right after raising it, the
+// part's workgroup LOOKS at the flags of the tile's other parts (no loop): whoever finds them all raised is (one of) the
+// last to arrive and adds the slots in ascending k into C.  Raising and looking are ordered like a sequentially consistent
+// store and load (sc1 store, s_waitcnt vmcnt(0), sc1 loads: how this target implements seq_cst at agent scope), so of two
+// parts finishing at the same moment at least one sees the other; if both do, both write the same bits to C (the gather
+// reads slots only, never C: idempotent).  No workgroup ever depends on another one being resident, so the form is sound next
+// to anything else on the device; the additions and their order are those of the other two forms: bit-identical.  A
+// workgroup owns two slots and two flags: index 2w for its first segment (a higher part of some tile), 2w + 1 for its last
+// one (the lowest-k part of another tile).
+enum class Combine { FixupKernel, HandOver, LastArriver };
+
+template <typename G, Combine MODE>
 __global__ __launch_bounds__(G::THREADS, G::MIN_WAVES) void mfma_f32_streamk_ordered_kernel(
     const float *__restrict__ A, const float *__restrict__ B, float *__restrict__ C, unsigned N, unsigned K, unsigned M,
     unsigned tiles_n, unsigned tiles_m, unsigned spt, unsigned sr, unsigned sc, unsigned teams_per_xcd, unsigned teams,
     float *__restrict__ slots, unsigned long long *__restrict__ flags, unsigned long long epoch) {
+  constexpr bool HANDOVER = MODE == Combine::HandOver, ARRIVE = MODE == Combine::LastArriver;
+  __shared__ unsigned gather_here;   // LastArriver: thread 0's verdict for the workgroup
   const unsigned lanes = sr * sc, xcd = blockIdx.x % 8, place = blockIdx.x / 8;
   const unsigned team_in_xcd = place / lanes, lane = place % lanes;
   const unsigned team = team_in_xcd * 8 + xcd, w = team * lanes + lane;   // consecutive teams on consecutive XCDs: fewer teams than places still use all eight
@@ -882,6 +897,48 @@ __global__ __launch_bounds__(G::THREADS, G::MIN_WAVES) void mfma_f32_streamk_ord
     const float *a = A + kbeg, *b = B + (size_t)kbeg * M;
     if (s0 == 0 && s1 == spt) {
       tile_body<G, false>(a, b, C, N, klen, M, K, M, N, M, row0, col0);
+    } else if constexpr (ARRIVE) {
+      // a part of a cut tile.  The tile's parts belong to teams t0 (lowest k: that team's LAST segment, slot / flag 2w' + 1)
+      // and t0 + 1 .. t_end - 1 (their FIRST segments, slot / flag 2w'), same lane.
+      const unsigned u_lo = st * spt, u_hi = u_lo + spt;
+      unsigned t0 = team;
+      while (t0 > 0 && sk_range_begin(units, t0, teams) > u_lo) --t0;
+      unsigned t_end = team + 1;
+      while (t_end < teams && sk_range_begin(units, t_end, teams) < u_hi) ++t_end;
+      auto part_index = [&](unsigned o) { return 2u * (o * lanes + lane) + (o == t0 ? 1u : 0u); };
+      const unsigned mine = part_index(team);
+      float *slot = slots + (size_t)mine * (G::BM * G::BN);
+      float *base = (float *)((unsigned long long)slot - ((unsigned long long)row0 * G::BN + col0) * sizeof(float));
+      tile_body<G, false, true>(a, b, base, N, klen, M, K, G::BN, ~0u, ~0u, row0, col0);   // slot stores at agent scope
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every wavefront: its slot stores have reached the agent's coherence point
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        __hip_atomic_store(flags + mine, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // raised = holds this launch's epoch
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the flag is out before the others' flags are looked at (store -> load order)
+        unsigned all = 1;
+        for (unsigned o = t0; o < t_end; ++o)
+          if (o != team && __hip_atomic_load(flags + part_index(o), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) all = 0;
+        if (all) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        gather_here = all;
+      }
+      __syncthreads();
+      if (gather_here) {   // (one of) the last to arrive: C = slot(t0) + slot(t0 + 1) + ... in ascending k, from slots only
+        constexpr int QUADS = G::BM * G::BN / 4 / G::THREADS;
+        f32x4 acc[QUADS];
+        const f32x4 *first = (const f32x4 *)(slots + (size_t)part_index(t0) * (G::BM * G::BN));
+#pragma unroll
+        for (int i = 0; i < QUADS; ++i) acc[i] = first[i * G::THREADS + threadIdx.x];
+        for (unsigned o = t0 + 1; o < t_end; ++o) {
+          const f32x4 *src = (const f32x4 *)(slots + (size_t)part_index(o) * (G::BM * G::BN));
+#pragma unroll
+          for (int i = 0; i < QUADS; ++i) acc[i] += src[i * G::THREADS + threadIdx.x];
+        }
+#pragma unroll
+        for (int i = 0; i < QUADS; ++i) {
+          const unsigned q = i * G::THREADS + threadIdx.x, row = row0 + q / (G::BN / 4), col = col0 + (q % (G::BN / 4)) * 4;
+          if (row < N && col < M) *(f32x4 *)(C + (size_t)row * M + col) = acc[i];
+        }
+      }
     } else if (s0 > 0) {   // not the lowest-k segment: this workgroup's first segment -> its slot, then the flag
       float *slot = slots + (size_t)w * (G::BM * G::BN);
       float *base = (float *)((unsigned long long)slot - ((unsigned long long)row0 * G::BN + col0) * sizeof(float));
@@ -891,7 +948,7 @@ __global__ __launch_bounds__(G::THREADS, G::MIN_WAVES) void mfma_f32_streamk_ord
         __syncthreads();
         if (threadIdx.x == 0) __hip_atomic_store(flags + w, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // raised = holds this launch's epoch
       }
-    } else if constexpr (!HANDOVER) {   // the lowest-k segment of a split tile: into C; the fix-up kernel adds the others
+    } else if constexpr (MODE == Combine::FixupKernel) {   // the lowest-k segment of a split tile: into C; the fix-up kernel adds the others
       tile_body<G, false>(a, b, C, N, klen, M, K, M, N, M, row0, col0);
     } else {               // the lowest-k segment of a split tile: this one into C, then the others on top in ascending k
       tile_body<G, false>(a, b, C, N, klen, M, K, M, N, M, row0, col0);
@@ -993,16 +1050,15 @@ static TeamPlan streamk_team_plan(const Problem &p) {
   return t;
 }
 
-// Stream-K as MM_PATH_AUTO runs it (f32_splitk 0): teams, slots, and the fix-up kernel.  No workgroup waits for another
-// one, so it is sound wherever a kernel is -- next to any other launch of any process, on a CU-masked stream, on a
-// partition, inside a graph -- and its bits are the hand-over form's.
+// The two-kernel teams form (f32_splitk 11; the cross-check of the default): teams, slots, and the fix-up kernel.  No
+// workgroup waits for another one either; the bits of the other two teams forms.
 template <typename G>
 int launch_streamk_teams(hipStream_t s, const Problem &p) {
   const TeamPlan t = streamk_team_plan<G>(p);
   const unsigned nwg = 512;
   static_assert(G::MIN_WAVES == 2, "two workgroups per CU: 64 places per XCD");
   static unsigned long long configured = 0;
-  if (int e = ensure_dynamic_lds((const void *)mfma_f32_streamk_ordered_kernel<G, false>, G::LDS_BYTES, configured)) return e;
+  if (int e = ensure_dynamic_lds((const void *)mfma_f32_streamk_ordered_kernel<G, Combine::FixupKernel>, G::LDS_BYTES, configured)) return e;
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return (int)e;
@@ -1013,7 +1069,7 @@ int launch_streamk_teams(hipStream_t s, const Problem &p) {
   if ((e = hipMallocFromPoolAsync((void **)&slots, slot_bytes, pool, s)) != hipSuccess) return (int)e;
   if (tuning(TUNE_DEBUG_POISON) == 1 && (e = hipMemsetAsync(slots, 0xFF, slot_bytes, s)) != hipSuccess) { (void)hipFreeAsync(slots, s); return (int)e; }   // NaN everywhere
   (void)hipGetLastError();
-  hipLaunchKernelGGL((mfma_f32_streamk_ordered_kernel<G, false>), dim3(nwg), dim3(G::THREADS), G::LDS_BYTES, s, (const float *)p.a,
+  hipLaunchKernelGGL((mfma_f32_streamk_ordered_kernel<G, Combine::FixupKernel>), dim3(nwg), dim3(G::THREADS), G::LDS_BYTES, s, (const float *)p.a,
                      (const float *)p.b, (float *)p.c, p.n, p.k, p.m, t.tiles_n, t.tiles_m, t.spt, t.sr, t.sc, t.teams_per_xcd, t.teams,
                      slots, (unsigned long long *)nullptr, 0ull);
   int rc = (int)hipGetLastError();
@@ -1026,6 +1082,39 @@ int launch_streamk_teams(hipStream_t s, const Problem &p) {
   return rc ? rc : (int)f;
 }
 
+// Stream-K as MM_PATH_AUTO runs it (f32_splitk 0): teams, two slots and two flags per workgroup, the last part to arrive
+// gathers -- one kernel, no workgroup waits for another one (Combine::LastArriver above).  Flags hold the launch's epoch
+// (flags_alloc, mm_capi.hip), so nothing is cleared between launches.
+template <typename G>
+int launch_streamk_arrive(hipStream_t s, const Problem &p) {
+  const TeamPlan t = streamk_team_plan<G>(p);
+  const unsigned nwg = 512;
+  static_assert(G::MIN_WAVES == 2, "two workgroups per CU: 64 places per XCD");
+  static unsigned long long configured = 0;
+  if (int e = ensure_dynamic_lds((const void *)mfma_f32_streamk_ordered_kernel<G, Combine::LastArriver>, G::LDS_BYTES, configured)) return e;
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return (int)e;
+  hipMemPool_t pool = nullptr;
+  if (int rc = workspace_pool(dev, &pool)) return rc;
+  float *slots = nullptr;
+  void *flags = nullptr;
+  unsigned long long epoch = 0;
+  const size_t slot_bytes = (size_t)2 * nwg * G::BM * G::BN * sizeof(float);
+  int rc = (int)hipMallocFromPoolAsync((void **)&slots, slot_bytes, pool, s);
+  if (rc == 0 && tuning(TUNE_DEBUG_POISON) == 1) rc = (int)hipMemsetAsync(slots, 0xFF, slot_bytes, s);   // NaN everywhere
+  if (rc == 0) rc = flags_alloc(dev, s, (size_t)2 * nwg * sizeof(unsigned long long), &flags, &epoch);
+  if (rc == 0) {
+    (void)hipGetLastError();
+    hipLaunchKernelGGL((mfma_f32_streamk_ordered_kernel<G, Combine::LastArriver>), dim3(nwg), dim3(G::THREADS), G::LDS_BYTES, s,
+                       (const float *)p.a, (const float *)p.b, (float *)p.c, p.n, p.k, p.m, t.tiles_n, t.tiles_m, t.spt, t.sr, t.sc,
+                       t.teams_per_xcd, t.teams, slots, (unsigned long long *)flags, epoch);
+    rc = (int)hipGetLastError();
+  }
+  const hipError_t f1 = flags ? hipFreeAsync(flags, s) : hipSuccess, f2 = slots ? hipFreeAsync(slots, s) : hipSuccess;
+  return rc ? rc : f1 != hipSuccess ? (int)f1 : (int)f2;
+}
+
 // The hand-over form (f32_splitk 10, opt-in): one kernel, the gather overlapped with other teams' work.  Needs the whole
 // chip to itself among launches of its kind IN EVERY PROCESS that shares the device -- the library can only order the ones
 // of this process (StreamkTicket, mm_capi.hip) -- which is why MM_PATH_AUTO no longer takes it (VERDICT r4
@@ -1036,7 +1125,7 @@ int launch_streamk_ordered(hipStream_t s, const Problem &p) {
   const unsigned nwg = 512;
   static_assert(G::MIN_WAVES == 2, "two workgroups per CU: 64 places per XCD");
   static unsigned long long configured = 0;
-  if (int e = ensure_dynamic_lds((const void *)mfma_f32_streamk_ordered_kernel<G, true>, G::LDS_BYTES, configured)) return e;
+  if (int e = ensure_dynamic_lds((const void *)mfma_f32_streamk_ordered_kernel<G, Combine::HandOver>, G::LDS_BYTES, configured)) return e;
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return (int)e;
@@ -1057,7 +1146,7 @@ int launch_streamk_ordered(hipStream_t s, const Problem &p) {
     refused = rc == 0 && !ticket.admitted();
     if (rc == 0 && ticket.admitted()) {
       (void)hipGetLastError();
-      hipLaunchKernelGGL((mfma_f32_streamk_ordered_kernel<G, true>), dim3(nwg), dim3(G::THREADS), G::LDS_BYTES, s, (const float *)p.a,
+      hipLaunchKernelGGL((mfma_f32_streamk_ordered_kernel<G, Combine::HandOver>), dim3(nwg), dim3(G::THREADS), G::LDS_BYTES, s, (const float *)p.a,
                          (const float *)p.b, (float *)p.c, p.n, p.k, p.m, t.tiles_n, t.tiles_m, t.spt, t.sr, t.sc, t.teams_per_xcd, t.teams,
                          slots, (unsigned long long *)flags, epoch);
       rc = (int)hipGetLastError();
@@ -1065,7 +1154,7 @@ int launch_streamk_ordered(hipStream_t s, const Problem &p) {
     }
   }   // ~StreamkTicket: records the event the next launch of this kind waits on, hands the ticket back
   const hipError_t f1 = flags ? hipFreeAsync(flags, s) : hipSuccess, f2 = slots ? hipFreeAsync(slots, s) : hipSuccess;
-  if (rc == 0 && refused) return launch_streamk_teams<G>(s, p);
+  if (rc == 0 && refused) return launch_streamk_arrive<G>(s, p);
   return rc ? rc : f1 != hipSuccess ? (int)f1 : (int)f2;
 }
 
@@ -1418,8 +1507,8 @@ int mfma_f32_resolve(const Problem &p, int variant) {
 // leave a quarter or more of the CUs without a workgroup (<= 192 tiles), K is cut into S = min(slots / tiles, K / 256, 8) chunks, the S copies of the tile grid run
 // side by side and a second kernel adds the S partial planes in ascending order -- deterministic, run to run and
 // whatever the placement, but a different summation order than the unsplit kernel (as accurate or better: shorter
-// chains).  f32_splitk: -1 this rule (and stream-K by streamk_wins), 0 stream-K (teams + fix-up kernel), 1 neither, 2..8 that many chunks, 9 stream-K in single ranges
-// with its fix-up kernel (cross-check), 10 stream-K with the hand-over inside the launch (opt-in; same bits as 0) (always only
+// chains).  f32_splitk: -1 this rule (and stream-K by streamk_wins), 0 stream-K (teams; the last part to arrive gathers), 1 neither, 2..8 that many chunks, 9 stream-K in
+// single ranges with its fix-up kernel (cross-check), 10 / 11 the teams form with the waiting hand-over (opt-in) / with a fix-up kernel (cross-check): the bits of 0 (always only
 // for row-major A and variant 35).  Row slabs of a bigger job (Problem::n_total) never take stream-K: its unit ranges would
 // depend on the slab, and with them a row's summation order.
 int mfma_f32_splitk(const Problem &p, int variant) {
@@ -1433,7 +1522,7 @@ int mfma_f32_splitk(const Problem &p, int variant) {
   if (variant != 35) return 1;
   const int knob = tuning(TUNE_F32_SPLITK);
   const unsigned long long sk_units = (unsigned long long)((p.n + 127) / 128) * ((p.m + 127) / 128) * (p.k / 32);   // the kernels count units in 32 bits
-  if (knob == 0 || knob == 9 || knob == 10) return (p.k % 32 == 0 && p.k >= 64 && sk_units < (1ull << 31)) ? knob : 1;   // stream-K forced: 0 = teams + fix-up kernel (the one auto takes), 9 = single ranges + fix-up kernel, 10 = teams with the hand-over inside the launch
+  if (knob == 0 || knob == 9 || knob == 10 || knob == 11) return (p.k % 32 == 0 && p.k >= 64 && sk_units < (1ull << 31)) ? knob : 1;   // stream-K forced: 0 = teams, last arriver gathers (the one auto takes), 11 = teams + fix-up kernel, 10 = teams with the waiting hand-over (opt-in), 9 = single ranges + fix-up kernel
   const unsigned rows = p.n_total ? p.n_total : p.n;   // of the whole job (Problem::n_total)
   const unsigned long long tiles = (unsigned long long)((rows + 127) / 128) * ((p.m + 127) / 128);
   unsigned s;
@@ -1492,7 +1581,8 @@ int launch_mfma_f32(hipStream_t s, const Problem &p, int variant) {
     case 8: return sdma_fits(p, 16) ? launch_geo<T256x256>(s, p) : launch_geo<T256x256v>(s, p);
     case 35: {
       const int splits = mfma_f32_splitk(p, v);
-      if (splits == 0) return sdma_fits(p, 32) ? launch_streamk_teams<T128x128>(s, p) : launch_streamk_teams<T128x128v>(s, p);
+      if (splits == 0) return sdma_fits(p, 32) ? launch_streamk_arrive<T128x128>(s, p) : launch_streamk_arrive<T128x128v>(s, p);
+      if (splits == 11) return sdma_fits(p, 32) ? launch_streamk_teams<T128x128>(s, p) : launch_streamk_teams<T128x128v>(s, p);
       if (splits == 10) return sdma_fits(p, 32) ? launch_streamk_ordered<T128x128>(s, p) : launch_streamk_ordered<T128x128v>(s, p);
       if (splits == 9) return sdma_fits(p, 32) ? launch_streamk<T128x128>(s, p) : launch_streamk<T128x128v>(s, p);
       return sdma_fits(p, 32) ? launch_geo<T128x128>(s, p, (unsigned)splits) : launch_geo<T128x128v>(s, p, (unsigned)splits);

@@ -223,10 +223,12 @@ int mm_kernel_info(const mm_config_t *cfg, unsigned size_n, unsigned size_k, uns
  * "band_rows", "f32_splitk"; -1 = the library's own choice).  Kernel ids of this library: f32_variant 33 / 8 / 35 / 64 (the
  * geometries of the shape-adaptive pick) and 0 / 3 (cross-checks); f16_variant 200 / 100 / 11 / 0 / 4 / 5; i8_variant 200 /
  * 100 / 10 / 5 / 0; f64_variant 0-4 (4: the 64 x 64 geometry for small problems); f32_splitk 1 whole tiles, 2-8 K chunks,
- * 0 stream-K as MM_PATH_AUTO runs it (teams of workgroups, partial tiles through scratch slots, a small fix-up kernel adds
- * them in ascending k: no workgroup ever waits for another one, so it is sound next to anything else on the device, on
- * CU-masked streams, in graphs), 9 stream-K in single ranges with its own fix-up kernel (cross-check), 10 stream-K with the
- * hand-over INSIDE the launch (opt-in; the bits of 0, a few per cent faster on some mid-size shapes).  Form 10 has workgroups
+ * 0 stream-K as MM_PATH_AUTO runs it: teams of workgroups, every part of a tile that a range boundary cuts goes to a scratch
+ * slot and raises a flag, and the LAST part to arrive adds the slots in ascending k into C -- one kernel in which no workgroup
+ * ever waits for another one, so it is sound next to anything else on the device (other streams, other processes), on
+ * CU-masked streams, on partitions and in graphs; 11 the same with a small fix-up kernel doing the gather (cross-check), 10
+ * the same with the owner of the lowest-k part WAITING for the others' flags inside the launch (opt-in) -- 0, 10 and 11 give
+ * the same bits; 9 stream-K in single ranges with its own fix-up kernel (cross-check, its own bits).  Form 10 has workgroups
  * wait for each other inside one launch; the library runs it only where that is sound as far as it can see -- a device
  * reporting 256 compute units, a stream without a CU mask, not under stream capture, never two such launches of THIS
  * PROCESS at once (each is ordered behind the previous one on the device with an event) -- and runs form 0 otherwise.  It

@@ -223,13 +223,14 @@ def test_f32_split_k_for_small_problems_is_deterministic_and_accurate(shape, spl
 def test_f32_stream_k_for_partial_rounds_is_deterministic_and_accurate(shape, forced):
     """Problems of a few partial rounds of 128 x 128 tiles are dealt out to 512 persistent workgroups in equal ranges of
     (tile, slab) units -- to teams of up to 4 x 4 workgroups on neighbouring tiles, so that an XCD's L2 still shares the
-    slabs.  A tile cut by a range boundary: the lowest-k part goes to C, the other parts to scratch slots, and the slots
-    are added on top in ascending k -- by a small second kernel in the form MM_PATH_AUTO runs (f32_splitk 0; round 5: no
-    workgroup ever waits for another one), inside the launch behind epoch flags in the opt-in hand-over form
-    (f32_splitk 10).  The two forms perform the same additions in the same order: BIT-IDENTICAL.  Same bits on every
-    launch; inside the fp32 bound; picked by the shape-adaptive rule where it pays (`auto` cases) and forcible (ragged
-    N / M, K of 3 slabs, ranges shorter than a tile, one tile cut 512 ways).  f32_splitk = 9 is the single-range form
-    with its own fix-up kernel: an independent implementation of the same idea (different cut points, different bits)."""
+    slabs.  A tile cut by a range boundary is finished in ascending k from scratch slots, in three interchangeable ways:
+    the LAST PART TO ARRIVE gathers (what MM_PATH_AUTO runs, f32_splitk 0: one kernel, every part raises a flag and then
+    looks at the others' -- nobody waits); a small second kernel gathers (11); the owner of the lowest-k part WAITS for the
+    others' flags and gathers (10, opt-in).  All three perform the same additions in the same order: BIT-IDENTICAL.  Same
+    bits on every launch; inside the fp32 bound; picked by the shape-adaptive rule where it pays (`auto` cases) and
+    forcible (ragged N / M, K of 3 slabs, ranges shorter than a tile, one tile cut 512 ways).  f32_splitk = 9 is the
+    single-range form with its own fix-up kernel: an independent implementation of the same idea (different cut points,
+    different bits)."""
     n, k, m = shape
     rng = np.random.default_rng(k + n)
     a = rng.uniform(-3, 10, size=(n, k)).astype(np.float32)
@@ -246,6 +247,9 @@ def test_f32_stream_k_for_partial_rounds_is_deterministic_and_accurate(shape, fo
         g.set_tuning("f32_splitk", 10)
         name_handover = g.kernel_name(g.make_config("float"), n, k, m)
         c_handover = [g.matmul_capi(a, b)[0] for _ in range(2)]
+        g.set_tuning("f32_splitk", 11)
+        name_two = g.kernel_name(g.make_config("float"), n, k, m)
+        c_two = [g.matmul_capi(a, b)[0] for _ in range(2)]
         g.set_tuning("f32_splitk", 9)
         name_fixup = g.kernel_name(g.make_config("float"), n, k, m)
         c_fixup, _ = g.matmul_capi(a, b)
@@ -259,7 +263,9 @@ def test_f32_stream_k_for_partial_rounds_is_deterministic_and_accurate(shape, fo
     assert name_fixup == "mfma_f32_128x128x32_w4x2_streamk_fixup", name_fixup
     c1 = runs[0]
     assert np.array_equal(c1, runs[1]) and np.array_equal(c1, runs[2])
-    assert np.array_equal(c1, c_handover[0]) and np.array_equal(c1, c_handover[1]), "two-kernel teams form != hand-over form"
+    assert name_two == "mfma_f32_128x128x32_w4x2_streamk_two_kernels", name_two
+    assert np.array_equal(c1, c_handover[0]) and np.array_equal(c1, c_handover[1]), "last-arriver form != hand-over form"
+    assert np.array_equal(c1, c_two[0]) and np.array_equal(c1, c_two[1]), "last-arriver form != two-kernel form"
     # the bar first (BASELINE.json north_star, applied normwise on this mixed-sign data) ...
     for what, c in (("teams + fix-up", c1), ("single ranges + fix-up", c_fixup), ("unsplit", c_one)):
         _bounds.north_star(_bounds.normwise(c, exact, scale), f"{what} {n}x{k}x{m}")
@@ -284,7 +290,7 @@ def test_f32_stream_k_flags_need_no_clearing_between_launches_and_survive_a_rele
         b = torch.empty((k, m), device=dev).uniform_(-3, 10, generator=torch.Generator(device=dev).manual_seed(30 + i))
         assert g.kernel_name(g.make_config("float"), n, k, m).endswith("streamk")
         ops.append((a, b))
-        alone.append(g.matmul(a, b).clone())        # the two-kernel form MM_PATH_AUTO runs: the hand-over form must give its bits
+        alone.append(g.matmul(a, b).clone())        # the last-arriver form MM_PATH_AUTO runs (epoch flags too): the hand-over form must give its bits
     torch.cuda.synchronize()
     g.set_tuning("f32_variant", 35)
     g.set_tuning("f32_splitk", 10)                  # the opt-in hand-over form: the one with flags
@@ -300,13 +306,14 @@ def test_f32_stream_k_flags_need_no_clearing_between_launches_and_survive_a_rele
         g.set_tuning("f32_splitk", -1)
 
 
-@pytest.mark.parametrize("form", ["two_kernel", "handover"])
+@pytest.mark.parametrize("form", ["default", "handover"])
 def test_f32_stream_k_launches_sharing_the_chip_make_progress_and_keep_their_bits(form):
     """Two stream-K launches on two streams, plus a third stream of whole-tile launches, compete for the same CUs, so
-    neither has all of its workgroups resident.  two_kernel (what MM_PATH_AUTO runs): nobody waits inside a kernel, so
-    there is nothing to go wrong.  handover (f32_splitk 10, opt-in): a workgroup waits on flags of workgroups with higher
-    ids, and the library orders such launches one behind the other (StreamkTicket): each must still finish and give
-    the bits it gives alone.  Run under a watchdog: a hang here would otherwise take the box down with it."""
+    neither has all of its workgroups resident.  default (what MM_PATH_AUTO runs): the last part to arrive gathers, nobody
+    waits inside a kernel -- parts of one tile finish in any order, under any residency.  handover (f32_splitk 10, opt-in):
+    a workgroup waits on flags of workgroups with higher ids, and the library orders such launches one behind the other
+    (StreamkTicket): each must still finish and give the bits it gives alone.  Run under a watchdog: a hang here would
+    otherwise take the box down with it."""
     import torch
     dev = torch.device("cuda:0")
     shapes = [(2341, 2304, 2304), (3584, 512, 3584), (2048, 2048, 2048)]

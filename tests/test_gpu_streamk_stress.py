@@ -1,7 +1,8 @@
 """Stress of stream-K's partial-tile traffic (gemm_hls_amd/csrc/mm_mfma_f32.hip: mfma_f32_streamk_ordered_kernel) in BOTH of
-its forms -- `two_kernel` (what MM_PATH_AUTO runs since round 5: slots, then a fix-up kernel; nobody waits inside a kernel)
-and `handover` (f32_splitk 10, opt-in: partial tiles pass from workgroup to workgroup INSIDE a launch through scratch slots
-and epoch flags).  What a clean run cannot see:
+its forms -- `default` (what MM_PATH_AUTO runs since round 5: every part of a cut tile goes to a scratch slot and raises an epoch
+flag, the LAST part to arrive gathers; nobody waits inside the kernel), `two_kernel` (f32_splitk 11: a fix-up kernel gathers) and
+`handover` (f32_splitk 10, opt-in: the owner of the lowest-k part waits for the others' flags INSIDE the launch).  What a clean
+run cannot see:
 
   * a stale read of a slot that an EARLIER launch of the same operands wrote is bit-identical to the right answer.  So
     every launch here runs with the library's `debug_poison` knob: the slot pool is filled with NaN first, and a read of
@@ -41,14 +42,14 @@ def _knobs():
         g.set_tuning(knob, -1)
 
 
-def _run(a, b, forced, form="two_kernel"):
-    handover = form == "handover"
-    g.set_tuning("f32_variant", 35 if (forced or handover) else -1)
-    g.set_tuning("f32_splitk", 10 if handover else (0 if forced else -1))
+def _run(a, b, forced, form="default"):
+    pinned = {"handover": 10, "two_kernel": 11}.get(form)
+    g.set_tuning("f32_variant", 35 if (forced or pinned) else -1)
+    g.set_tuning("f32_splitk", pinned if pinned else (0 if forced else -1))
     return g.matmul(a, b)
 
 
-@pytest.mark.parametrize("form", ["two_kernel", "handover"])
+@pytest.mark.parametrize("form", ["default", "two_kernel", "handover"])
 def test_poisoned_slots_alternating_shapes_under_background_load(form):
     import torch
     dev = torch.device("cuda:0")
@@ -75,7 +76,7 @@ def test_poisoned_slots_alternating_shapes_under_background_load(form):
     g.set_tuning("debug_poison", 1)
     launches, bad = 0, []
     order = np.random.default_rng(7)
-    for rep in range(300 if form == "two_kernel" else 150):
+    for rep in range(300 if form == "default" else 120):
         with torch.cuda.stream(side):
             if rep % 3 == 0:
                 noise.add_(1.0)
@@ -92,7 +93,7 @@ def test_poisoned_slots_alternating_shapes_under_background_load(form):
             break
     torch.cuda.synchronize()
     assert not bad, f"hand-over read what this launch had not written (rep, shape, NaNs, differing elements): {bad[:4]}"
-    assert launches >= (2000 if form == "two_kernel" else 1000), launches
+    assert launches >= (2000 if form == "default" else 800), launches
 
 
 def test_poison_knob_really_poisons_and_the_fixup_form_passes_it_too():
@@ -106,7 +107,7 @@ def test_poison_knob_really_poisons_and_the_fixup_form_passes_it_too():
     a = torch.empty((n, k), device=dev).uniform_(-3, 10)
     b = torch.empty((k, m), device=dev).uniform_(-3, 10)
     g.set_tuning("f32_variant", 35)
-    for form in (9, 0):
+    for form in (9, 11, 0):
         g.set_tuning("debug_poison", -1)
         g.set_tuning("f32_splitk", form)
         plain = g.matmul(a, b).clone()
@@ -116,7 +117,7 @@ def test_poison_knob_really_poisons_and_the_fixup_form_passes_it_too():
         assert not bool(torch.isnan(plain).any())
 
 
-@pytest.mark.parametrize("form", ["two_kernel", "handover"])
+@pytest.mark.parametrize("form", ["default", "handover"])
 def test_two_host_threads_on_two_streams_keep_their_bits_and_finish(form):
     """Two host threads, each with its own stream, launch stream-K shapes at the same time (poisoned slots); a third
     thread keeps whole-tile launches running next to them.  handover (MM_F32_SPLITK=10 semantics, set through the knob for
@@ -140,7 +141,7 @@ def test_two_host_threads_on_two_streams_keep_their_bits_and_finish(form):
         g.set_tuning("f32_variant", 35)
         g.set_tuning("f32_splitk", 10)
         for i, op in enumerate(ops):
-            assert torch.equal(g.matmul(*op), alone[i])      # the hand-over form gives the two-kernel form's bits
+            assert torch.equal(g.matmul(*op), alone[i])      # the hand-over form gives the default form's bits
     whole = g.matmul(wa, wb).clone()
     torch.cuda.synchronize()
     g.set_tuning("debug_poison", 1)
@@ -187,7 +188,7 @@ n, k, m = 2341, 2304, 2304
 a = torch.empty((n, k), device=dev).uniform_(-3, 10)
 b = torch.empty((k, m), device=dev).uniform_(-3, 10)
 assert g.kernel_name(g.make_config("float"), n, k, m).endswith("streamk")
-two_kernel = g.matmul(a, b).clone()
+two_kernel = g.matmul(a, b).clone()                                  # (the default form: the last part to arrive gathers)
 g.set_tuning("f32_variant", 35); g.set_tuning("f32_splitk", 10)      # ask for the hand-over form ...
 handover = g.matmul(a, b).clone()
 torch.cuda.synchronize()
@@ -211,7 +212,7 @@ def test_cu_masked_stream_gets_the_two_kernel_form_and_finishes():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     if "SKIP" in r.stdout:
         pytest.skip(r.stdout.strip())
-    # ... on a CU-masked stream the ticket is refused and the two-kernel form runs (it finished: we are here), same bits
+    # ... on a CU-masked stream the ticket is refused and the default (wait-free) form runs (it finished: we are here), same bits
     assert "masked==two_kernel True" in r.stdout and "handover==two_kernel True" in r.stdout, r.stdout
 
 
@@ -245,7 +246,7 @@ print("DONE bad", bad, "checksum", [float(c.double().sum()) for c in alone], flu
 def test_two_processes_sharing_the_gpu_run_stream_k_side_by_side():
     """VERDICT r4 weak 6 / ADVICE r4: two PROCESSES on one GPU (MPI ranks, pytest-xdist, MM_BENCH_DEVICE_MOD=1) each running
     stream-K shapes.  The library's per-device ordering of hand-over launches cannot reach across processes -- which is why
-    MM_PATH_AUTO no longer runs that form: the default form has no inter-workgroup wait, so two processes' launches
+    MM_PATH_AUTO no longer runs that form: the default form (the last part to arrive gathers) has no inter-workgroup wait, so two processes' launches
     interleave freely, finish, and give the same bits in both processes (same seeds) as alone."""
     code = _TWO_PROCESS_CHILD.format(root=ROOT)
     kids = [subprocess.Popen([sys.executable, "-c", code], stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT)

@@ -56,18 +56,22 @@ def ordered_kernels():
             kernels[name] = body
             name = None
     picked = {k: v for k, v in kernels.items() if "mfma_f32_streamk_ordered_kernel" in k}
-    assert len(picked) == 4, list(kernels)           # (scalar-base DMA, vector-address) x (hand-over, two-kernel)
+    assert len(picked) == 6, list(kernels)           # (scalar-base DMA, vector-address) x Combine::{FixupKernel, HandOver, LastArriver}
     _ALL["kernels"] = kernels
     _ALL["metadata"] = r.stdout
-    handover = {k: v for k, v in picked.items() if "Lb1EEEv" in k}      # <G, true>
-    assert len(handover) == 2, list(picked)
+    handover = _by_combine(1)
     return handover
 
 
-def _two_kernel_forms(ordered_kernels):
-    picked = {k: v for k, v in _ALL["kernels"].items() if "mfma_f32_streamk_ordered_kernel" in k and k not in ordered_kernels}
-    assert len(picked) == 2 and len(ordered_kernels) == 2, (list(picked), list(ordered_kernels))
+def _by_combine(value):
+    """The two instantiations (DMA forms) of mfma_f32_streamk_ordered_kernel<G, Combine(value)>: 0 FixupKernel, 1 HandOver, 2 LastArriver."""
+    picked = {k: v for k, v in _ALL["kernels"].items() if "mfma_f32_streamk_ordered_kernel" in k and f"CombineE{value}EEEv" in k}
+    assert len(picked) == 2, [k for k in _ALL["kernels"] if "streamk_ordered" in k]
     return picked
+
+
+def _two_kernel_forms(ordered_kernels):
+    return _by_combine(0)
 
 
 def _is(op, ins):
@@ -139,3 +143,35 @@ def test_no_shipped_matrix_core_kernel_of_this_unit_spills(ordered_kernels):
         assert not any(t.startswith("scratch_") for t in body), name
     sizes = re.findall(r"\.private_segment_fixed_size:\s*(\d+)", _ALL["metadata"])
     assert sizes and all(int(x) == 0 for x in sizes), sizes
+
+
+def test_the_last_arriver_form_is_wait_free_and_orders_raise_before_look(ordered_kernels):
+    """mfma_f32_streamk_ordered_kernel<G, Combine::LastArriver>, what MM_PATH_AUTO runs: every part stores its slot at agent scope
+    (sc1 + wait state), then s_waitcnt vmcnt(0) -> s_barrier -> ONE sc1 flag store -> s_waitcnt vmcnt(0) -> sc1 flag LOADS (the
+    store-then-load order of a sequentially consistent pair on this target) -> buffer_inv sc1 -> s_barrier -> the gather's loads.
+    And it never waits: no s_sleep, and no flag load sits in a loop that polls (the only backward branches after the flag store
+    are the loop over the tile's parts and the segment loop, both of which advance)."""
+    for name, body in _by_combine(2).items():
+        slot_stores = [i for i, t in enumerate(body) if _is("global_store_dwordx4", t) and t.endswith("sc1")]
+        assert len(slot_stores) >= 16, (name, len(slot_stores))
+        for i in slot_stores:
+            assert _is("s_nop", body[i + 1]), (name, body[i], body[i + 1])
+        flag = [i for i, t in enumerate(body) if _is("global_store_dwordx2", t)]
+        assert len(flag) == 1 and body[flag[0]].endswith("sc1"), (name, [body[i] for i in flag])
+        i = flag[0]
+        back = body[max(0, i - 40):i]
+        bar = max(j for j, t in enumerate(back) if _is("s_barrier", t))
+        assert not any(t.startswith("global_store") or t.startswith("buffer_store") for t in back[bar:]), (name, back[bar:])
+        assert any(_is("s_waitcnt", t) and "vmcnt(0)" in t for t in back[:bar]), (name, back)
+        after = body[i + 1:]
+        looks = [j for j, t in enumerate(after) if _is("global_load_dwordx2", t)]
+        assert looks and all(after[j].endswith("sc1") for j in looks), (name, [after[j] for j in looks])
+        assert any(_is("s_waitcnt", t) and "vmcnt(0)" in t for t in after[:looks[0]]), (name, after[:looks[0]])   # raise completes before the first look
+        inv = [j for j, t in enumerate(after) if t == "buffer_inv sc1"]
+        assert len(inv) == 1 and inv[0] > looks[0], (name, inv, looks)
+        rest = after[inv[0] + 1:]
+        first_barrier = next(j for j, t in enumerate(rest) if _is("s_barrier", t))
+        first_gather = next(j for j, t in enumerate(rest) if _is("global_load_dwordx4", t))
+        assert first_barrier < first_gather, (name, first_barrier, first_gather)
+        assert not any(_is("s_sleep", t) for t in body), name                      # nobody waits
+        assert not any("atomic" in t for t in body) and not any(_is("buffer_wbl2", t) for t in body), name

@@ -329,7 +329,7 @@ def test_streamk_ranges_random_configurations():
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-# Stream-K with the ordered hand-over inside the launch (mfma_f32_streamk_ordered_kernel / launch_streamk_ordered), replayed
+# Stream-K in teams (mfma_f32_streamk_ordered_kernel in its three Combine forms: hand-over, fix-up kernel, last arriver), replayed
 # with the kernel's integer formulas: teams of sr x sc workgroups walk equal ranges of (super-tile, slab) units; a segment
 # that does not begin a tile is its workgroup's FIRST one (-> slot + flag), a segment that begins a tile but does not end it
 # is its workgroup's LAST one (-> C, then waits for and adds the slots of the following teams' same lane).  Checked: every
@@ -415,6 +415,44 @@ def _ordered_replay(tiles_n, tiles_m, spt):
             else:
                 assert sources == lowest[(tile_r, tile_c)][1]
                 assert covered[((tile_r, tile_c), 0)] == t0 * lanes + lane       # C holds the part of the team the fix-up starts from
+    # The last-arriver form (Combine::LastArriver, what MM_PATH_AUTO runs): EVERY part of a cut tile -- whichever it is --
+    # derives the tile's part list (t0 .. t_end - 1) from its own team and segment, and the slot / flag index of each part
+    # (2w for a first segment, 2w + 1 for the lowest-k part = its owner's last segment).  All parts of a tile must derive
+    # the same list, the indices must be distinct across the launch, and the list must be the hand-over form's gather list.
+    used = {}
+    for block in range(512):
+        xcd, place = block % 8, block // 8
+        team_in_xcd, lane = place // lanes, place % lanes
+        team = team_in_xcd * 8 + xcd
+        if team_in_xcd >= tpx or team >= teams:
+            continue
+        u0, u1 = _sk_begin(units, team, teams), _sk_begin(units, team + 1, teams)
+        u = u0
+        while u < u1:
+            st = u // spt
+            s0 = u - st * spt
+            s1 = min(spt, s0 + (u1 - u))
+            u += s1 - s0
+            if s0 == 0 and s1 == spt:
+                continue
+            tile = ((st % st_rows) * sr + lane % sr, (st // st_rows) * sc + lane // sr)
+            u_lo, u_hi = st * spt, st * spt + spt
+            t0 = team
+            while t0 > 0 and _sk_begin(units, t0, teams) > u_lo:
+                t0 -= 1
+            t_end = team + 1
+            while t_end < teams and _sk_begin(units, t_end, teams) < u_hi:
+                t_end += 1
+            index = lambda o: 2 * (o * lanes + lane) + (1 if o == t0 else 0)
+            assert (s0 == 0) == (team == t0)                                     # the lowest-k part is t0's, and only t0's
+            assert [o * lanes + lane for o in range(t0 + 1, t_end)] == lowest[tile][1]
+            mine = index(team)
+            assert mine not in used and mine < 2 * 512                           # one writer per slot / flag in the launch
+            used[mine] = tile
+            for o in range(t0, t_end):                                           # every sibling it looks at really is a part of this tile
+                k_lo = max(_sk_begin(units, o, teams), u_lo) - u_lo
+                assert covered[(tile, k_lo)] == o * lanes + lane
+    assert len(used) == len(slot_of) + len(lowest)
     return sr, sc, teams
 
 

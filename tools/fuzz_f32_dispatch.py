@@ -33,13 +33,15 @@ for i in range(args.shapes):
     worst = max(worst, err)
     met[name.replace("mfma_f32_", "")] += 1
     if name.endswith("_streamk"):      # the opt-in hand-over form (f32_splitk 10) performs the same additions in the same order: same bits
-        g.set_tuning("f32_variant", 35); g.set_tuning("f32_splitk", 10)
+        g.set_tuning("f32_variant", 35)
         try:
-            assert g.kernel_name(g.make_config("float"), n, k, m).endswith("_streamk_handover")
-            assert torch.equal(g.matmul(a, b), c1), ("hand-over form != two-kernel form", (n, k, m))
+            for knob, tag in ((10, "_streamk_handover"), (11, "_streamk_two_kernels")):
+                g.set_tuning("f32_splitk", knob)
+                assert g.kernel_name(g.make_config("float"), n, k, m).endswith(tag)
+                assert torch.equal(g.matmul(a, b), c1), (tag + " != the default (last-arriver) form", (n, k, m))
         finally:
             g.set_tuning("f32_variant", -1); g.set_tuning("f32_splitk", -1)
-        met["(hand-over form == two-kernel form)"] += 1
+        met["(hand-over form == two-kernel form == default form)"] += 1
     if n % 4 == 0:
         at = a.t().contiguous()
         name_t = g.kernel_name(g.make_config("float", transposed_a=True), n, k, m)

@@ -14,4 +14,4 @@ def rate(s, sk, var):
 for s in sizes:
     t = (s + 127) // 128
     name = g.kernel_name(g.make_config("float"), s, s, s)
-    print(s, f"{t}x{t} tiles: auto", rate(s, -1, -1), "whole tiles", rate(s, 1, -1), "stream-K teams+fixup", rate(s, 0, 35), "hand-over", rate(s, 10, 35), "single-range fix-up", rate(s, 9, 35), " auto =", name, flush=True)
+    print(s, f"{t}x{t} tiles: auto", rate(s, -1, -1), "whole tiles", rate(s, 1, -1), "stream-K last-arriver", rate(s, 0, 35), "teams+fixup", rate(s, 11, 35), "hand-over", rate(s, 10, 35), "single-range fix-up", rate(s, 9, 35), " auto =", name, flush=True)
