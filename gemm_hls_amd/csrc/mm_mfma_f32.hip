@@ -1067,7 +1067,9 @@ int launch_streamk_teams(hipStream_t s, const Problem &p) {
   float *slots = nullptr;
   const size_t slot_bytes = (size_t)nwg * G::BM * G::BN * sizeof(float);
   if ((e = hipMallocFromPoolAsync((void **)&slots, slot_bytes, pool, s)) != hipSuccess) return (int)e;
-  if (tuning(TUNE_DEBUG_POISON) == 1 && (e = hipMemsetAsync(slots, 0xFF, slot_bytes, s)) != hipSuccess) { (void)hipFreeAsync(slots, s); return (int)e; }   // NaN everywhere
+  // debug_poison: NaN in every slot AND in C (pure output: a tile nobody finished then shows as NaN instead of as whatever the buffer held)
+  if (tuning(TUNE_DEBUG_POISON) == 1 && ((e = hipMemsetAsync(slots, 0xFF, slot_bytes, s)) != hipSuccess ||
+                                         (e = hipMemsetAsync(p.c, 0xFF, (size_t)p.n * p.m * sizeof(float), s)) != hipSuccess)) { (void)hipFreeAsync(slots, s); return (int)e; }
   (void)hipGetLastError();
   hipLaunchKernelGGL((mfma_f32_streamk_ordered_kernel<G, Combine::FixupKernel>), dim3(nwg), dim3(G::THREADS), G::LDS_BYTES, s, (const float *)p.a,
                      (const float *)p.b, (float *)p.c, p.n, p.k, p.m, t.tiles_n, t.tiles_m, t.spt, t.sr, t.sc, t.teams_per_xcd, t.teams,
@@ -1102,7 +1104,8 @@ int launch_streamk_arrive(hipStream_t s, const Problem &p) {
   unsigned long long epoch = 0;
   const size_t slot_bytes = (size_t)2 * nwg * G::BM * G::BN * sizeof(float);
   int rc = (int)hipMallocFromPoolAsync((void **)&slots, slot_bytes, pool, s);
-  if (rc == 0 && tuning(TUNE_DEBUG_POISON) == 1) rc = (int)hipMemsetAsync(slots, 0xFF, slot_bytes, s);   // NaN everywhere
+  if (rc == 0 && tuning(TUNE_DEBUG_POISON) == 1) rc = (int)hipMemsetAsync(slots, 0xFF, slot_bytes, s);   // debug_poison: NaN in every slot ...
+  if (rc == 0 && tuning(TUNE_DEBUG_POISON) == 1) rc = (int)hipMemsetAsync(p.c, 0xFF, (size_t)p.n * p.m * sizeof(float), s);   // ... and in C (pure output): an unfinished tile shows
   if (rc == 0) rc = flags_alloc(dev, s, (size_t)2 * nwg * sizeof(unsigned long long), &flags, &epoch);
   if (rc == 0) {
     (void)hipGetLastError();
@@ -1137,7 +1140,8 @@ int launch_streamk_ordered(hipStream_t s, const Problem &p) {
   unsigned long long epoch = 0;
   const size_t slot_bytes = (size_t)nwg * G::BM * G::BN * sizeof(float);
   int rc = (int)hipMallocFromPoolAsync((void **)&slots, slot_bytes, pool, s);
-  if (rc == 0 && tuning(TUNE_DEBUG_POISON) == 1) rc = (int)hipMemsetAsync(slots, 0xFF, slot_bytes, s);   // NaN everywhere
+  if (rc == 0 && tuning(TUNE_DEBUG_POISON) == 1) rc = (int)hipMemsetAsync(slots, 0xFF, slot_bytes, s);   // debug_poison: NaN in every slot ...
+  if (rc == 0 && tuning(TUNE_DEBUG_POISON) == 1) rc = (int)hipMemsetAsync(p.c, 0xFF, (size_t)p.n * p.m * sizeof(float), s);   // ... and in C (pure output): an unfinished tile shows
   if (rc == 0) rc = flags_alloc(dev, s, nwg * sizeof(unsigned long long), &flags, &epoch);
   bool refused = false;
   if (rc == 0) {
@@ -1206,7 +1210,9 @@ int launch_streamk(hipStream_t s, const Problem &p) {
   float *slots = nullptr;
   const size_t slot_bytes = (size_t)nwg * 2 * G::BM * G::BN * sizeof(float);
   if ((e = hipMallocFromPoolAsync((void **)&slots, slot_bytes, pool, s)) != hipSuccess) return (int)e;
-  if (tuning(TUNE_DEBUG_POISON) == 1 && (e = hipMemsetAsync(slots, 0xFF, slot_bytes, s)) != hipSuccess) { (void)hipFreeAsync(slots, s); return (int)e; }   // NaN everywhere
+  // debug_poison: NaN in every slot AND in C (pure output: a tile nobody finished then shows as NaN instead of as whatever the buffer held)
+  if (tuning(TUNE_DEBUG_POISON) == 1 && ((e = hipMemsetAsync(slots, 0xFF, slot_bytes, s)) != hipSuccess ||
+                                         (e = hipMemsetAsync(p.c, 0xFF, (size_t)p.n * p.m * sizeof(float), s)) != hipSuccess)) { (void)hipFreeAsync(slots, s); return (int)e; }
   (void)hipGetLastError();
   const unsigned kband = band_rows(G::BM, G::BN, G::MIN_WAVES);
   hipLaunchKernelGGL((mfma_f32_streamk_kernel<G>), dim3(nwg), dim3(G::THREADS), G::LDS_BYTES, s, (const float *)p.a, (const float *)p.b,

@@ -234,8 +234,8 @@ int mm_kernel_info(const mm_config_t *cfg, unsigned size_n, unsigned size_k, uns
  * PROCESS at once (each is ordered behind the previous one on the device with an event) -- and runs form 0 otherwise.  It
  * cannot see other processes: whoever sets f32_splitk = 10 vouches that no second process runs such launches on the same
  * device (two of them could each hold half the chip and wait for ever).
- * "debug_poison" = 1 fills the scratch that kernels hand partial tiles through with NaN before every launch (a read of
- * anything the launch did not write then shows in C; tests only).  "md_virtual_devices": see mm_gemm_multi_device.  Any
+ * "debug_poison" = 1 fills the scratch that kernels hand partial tiles through, and C itself (pure output), with NaN before
+ * every stream-K launch: a read of anything the launch did not write, or a tile nobody finished, then shows in C (tests only).  "md_virtual_devices": see mm_gemm_multi_device.  Any
  * other id is refused: the retired schedules and the work-skipping ablations of the measurement history exist only in the
  * lab build (tools/lab/libmm_gemm_amd_lab.so, built on request, where "ablations" = 1 unlocks the latter).  Each knob is
  * initialised ONCE from its environment variable (MM_F32_VARIANT, ...) and changed only through this call afterwards; the
