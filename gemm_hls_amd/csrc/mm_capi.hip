@@ -231,7 +231,7 @@ int mm::workspace_pool(int dev, hipMemPool_t *out) {
   return 0;
 }
 
-// Hand-over flags of the stream-K launches (mm_mfma_f32.hip: launch_streamk_ordered).  A flag is "raised" when it holds the
+// Flags of the stream-K launches (mm_mfma_f32.hip: launch_streamk_arrive).  A flag is "raised" when it holds the
 // launch's EPOCH, a process-wide 64-bit count that no two launches share, so flags never have to be lowered -- provided the
 // memory they live in has never held anything but zeros and epochs.  Hence a second pool of this library's own that
 // serves nothing else, every block of it cleared (stream-ordered) the first time its address is handed out.  That saves
@@ -274,73 +274,6 @@ int mm::flags_alloc(int dev, hipStream_t s, size_t bytes, void **out, unsigned l
     if ((e = hipMemsetAsync(*out, 0, bytes, s)) != hipSuccess) { (void)hipFreeAsync(*out, s); return (int)e; }
   }
   return 0;
-}
-
-// Stream-K with the hand-over inside the launch (mm_mfma_f32.hip: mfma_f32_streamk_ordered_kernel<G, true>; opt-in through
-// f32_splitk = 10, never taken by MM_PATH_AUTO) has workgroups wait on flags that other workgroups of the SAME launch raise.
-// That is only sound when every workgroup of the launch gets a place on the chip without one of the waiting ones having to
-// leave first:
-//   * the device has the 256 CUs (8 XCDs x 32) the launch's 512 places are counted on, and the stream is not CU-masked;
-//   * no second launch of that kind competes for the places: two of them, each holding part of the chip with workgroups
-//     that wait for workgroups the other one keeps from being dispatched, would wait for ever.  So such
-//     launches are serialised per device: each one's stream first waits for the event recorded behind the previous one
-//     (ordinary kernels next to it are fine -- they finish and hand their places over).  This orders the launches of THIS
-//     PROCESS only; whoever opts in vouches that no other process runs such launches on the device;
-//   * the stream is not being captured: replays of a graph are launched by the application, outside this ordering.
-// Where any of this does not hold, the ticket is refused and the launcher runs the two-kernel teams form (same bits).
-namespace {
-struct StreamkDeviceState {
-  std::mutex mu;                     // per device: host threads driving different GPUs do not meet here
-  hipEvent_t event = nullptr;        // recorded behind the last hand-over launch
-  hipStream_t stream = nullptr;      // ... on this stream
-  bool any = false;
-};
-StreamkDeviceState g_streamk[64];
-}  // namespace
-
-mm::StreamkTicket::StreamkTicket(int dev, hipStream_t s) : device_(dev), stream_(s) {
-  if (dev < 0 || dev >= 64 || g_device_cus[dev] != 256) return;
-  hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
-  hipError_t e = hipStreamIsCapturing(s, &capture);
-  if (e != hipSuccess) { error_ = (int)e; return; }
-  if (capture != hipStreamCaptureStatusNone) return;
-  uint32_t mask[8] = {};
-  e = hipExtStreamGetCUMask(s, 8, mask);
-  if (e == hipSuccess) {
-    int cus = 0;
-    for (uint32_t w : mask) cus += __builtin_popcount(w);
-    if (cus != 256) return;
-  } else {
-    (void)hipGetLastError();
-    if (s != nullptr) return;        // a stream whose mask cannot be read is treated as masked; the null stream has none of its own
-  }
-  // From here to the destructor the device's ticket is held: wait-for-previous, launch and record-behind-it are one step,
-  // or two host threads on two streams could both wait for the SAME earlier event and then run side by side.
-  StreamkDeviceState &st = g_streamk[dev];
-  st.mu.lock();
-  if (!st.event && (e = hipEventCreateWithFlags(&st.event, hipEventDisableTiming)) != hipSuccess) {
-    st.event = nullptr;
-    st.mu.unlock();
-    error_ = (int)e;
-    return;
-  }
-  if (st.any && st.stream != s && (e = hipStreamWaitEvent(s, st.event, 0)) != hipSuccess) {
-    st.mu.unlock();
-    error_ = (int)e;
-    return;
-  }
-  admitted_ = true;
-}
-
-mm::StreamkTicket::~StreamkTicket() {
-  if (!admitted_) return;
-  StreamkDeviceState &st = g_streamk[device_];
-  if (launched_) {
-    (void)hipEventRecord(st.event, stream_);
-    st.stream = stream_;
-    st.any = true;
-  }
-  st.mu.unlock();
 }
 
 int mm::device_compute_units(int dev) { return dev >= 0 && dev < 64 && g_device_cus[dev] > 0 ? g_device_cus[dev] : 256; }
@@ -764,7 +697,6 @@ const char *mm_kernel_name(const mm_config_t *cfg, unsigned n, unsigned k, unsig
       }
       if (splits == 0) return "mfma_f32_128x128x32_w4x2_streamk";            // teams, the last part to arrive gathers: what MM_PATH_AUTO runs
       if (splits == 9) return "mfma_f32_128x128x32_w4x2_streamk_fixup";      // single ranges + fix-up kernel (cross-check, its own bits)
-      if (splits == 10) return "mfma_f32_128x128x32_w4x2_streamk_handover";  // opt-in waiting form; the bits of `streamk`
       if (splits == 11) return "mfma_f32_128x128x32_w4x2_streamk_two_kernels";   // teams + fix-up kernel (cross-check); the bits of `streamk`
       return splits > 1 ? split_names[splits] : mm::mfma_f32_name(v);
     }

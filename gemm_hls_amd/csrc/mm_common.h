@@ -95,29 +95,8 @@ size_t mfma_f32_split_workspace_bytes(const Problem &p);
 int mfma_f32_split_tile(const Problem &p, int variant);  // 256 or 128
 int workspace_pool(int device, hipMemPool_t *pool);      // the library-owned, stream-ordered workspace pool of `device` (mm_capi.hip)
 int workspace_release(int device);                       // hands its cached memory back to the driver
-// `bytes` of hand-over flags for one launch on `stream` (free with hipFreeAsync), and the launch's epoch: mm_capi.hip
+// `bytes` of epoch flags for one stream-K launch on `stream` (free with hipFreeAsync), and the launch's epoch: mm_capi.hip
 int flags_alloc(int device, hipStream_t stream, size_t bytes, void **flags, unsigned long long *epoch);
-// Stream-K's in-launch hand-over (opt-in, f32_splitk 10) needs the whole chip and no second launch of its kind next to it
-// (mm_capi.hip).  The ticket is the device's one-at-a-time token for such launches: constructing it checks the device and
-// the stream and, if admitted(), has ordered `stream` behind the previous launch of that kind and HOLDS the device's
-// stream-K mutex; the destructor records the event the next one waits on (if launched() was called) and lets go -- on
-// every path, whatever returns early in between.  Not admitted (or error() != 0): nothing is held; run the two-kernel form.
-class StreamkTicket {
- public:
-  StreamkTicket(int device, hipStream_t stream);
-  ~StreamkTicket();
-  StreamkTicket(const StreamkTicket &) = delete;
-  StreamkTicket &operator=(const StreamkTicket &) = delete;
-  bool admitted() const { return admitted_; }
-  int error() const { return error_; }
-  void launched() { launched_ = true; }
-
- private:
-  int device_;
-  hipStream_t stream_;
-  bool admitted_ = false, launched_ = false;
-  int error_ = 0;
-};
 int device_compute_units(int device);                    // as reported by the device when the library initialised
 int mfma_f32_splitk(const Problem &p, int variant);      // K chunks the fp32 MFMA launcher uses for (problem, resolved variant)
 bool mfma_f32_serves(const Problem &p);

@@ -124,9 +124,9 @@ __device__ __forceinline__ void tile_body(const float *__restrict__ A, const flo
   constexpr bool TWO_LEVEL = G::CHAIN == Chain::TwoLevel, FLUSH = G::CHAIN == Chain::FlushIntoC;
   constexpr bool PIPELINED = G::READS == Reads::Pipelined, SDMA = G::DMA == Dma::ScalarBase;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  // AGENT_STORES (the scratch slot of a stream-K hand-over, read by a workgroup on another XCD): the predicated stores go out
-  // at agent scope (sc1: written through this XCD's L2 to the agent's coherence point), so that the hand-over needs no
-  // write-back of the whole L2 -- see mfma_f32_streamk_ordered_kernel.  Inline asm, because the language has no 16-byte
+  // AGENT_STORES (a stream-K scratch slot, read by a workgroup on another XCD): the predicated stores go out
+  // at agent scope (sc1: written through this XCD's L2 to the agent's coherence point), so that handing it over needs no
+  // write-back of the whole L2 -- see mfma_f32_streamk_teams_kernel.  Inline asm, because the language has no 16-byte
   // scoped store; the compiler's hazard recogniser does not look inside it, so the wait state a store of more than 8 bytes
   // needs before its data registers are written again (the compiler inserts it for its own stores) is part of the statement.
   static_assert(!AGENT_STORES || G::TM == 1, "agent-scope stores are wired into the predicated write-back only");
@@ -829,23 +829,8 @@ __global__ __launch_bounds__(G::THREADS, G::MIN_WAVES) void mfma_f32_streamk_ker
   }
 }
 
-// Stream-K in TEAMS (what the shape-adaptive rule and f32_splitk = 0 run, as two kernels -- see HANDOVER below; 9 = the single-range
-// form above, kept as its cross-check), here first in its one-kernel form with the combine inside the launch ("ordered
-// hand-over", f32_splitk = 10, opt-in).  Same unit ranges.  Observation: every
-// segment of a tile other than its lowest-k one is the FIRST segment of the workgroup that owns it (a range enters a tile
-// from below only at its own start), and the lowest-k segment is the LAST thing its owner does.  So: the others write
-// their scratch slot and raise a flag right away; the owner of the lowest-k segment writes its sum to C, waits for those
-// flags (raised by first segments, normally long ago) and adds the slots on top in ascending k -- C = own + slot + slot ...
-// A fixed order, no atomics on data, no second kernel and half the scratch.  Waits point at higher workgroup ids only,
-// are the last thing a workgroup does and never aim at a segment that itself waits.  FORWARD PROGRESS is nevertheless a
-// property of the launch, not of the kernel: a waiting workgroup keeps its place on its CU, so every workgroup it waits
-// for must find a place without it leaving -- true when all 512 workgroups fit the chip at once (256 CUs x 2) next to
-// kernels that finish on their own, false on a CU-masked stream, on a partitioned device, or next to a second launch of
-// this kind -- of ANY process sharing the device -- (each holding places the other's producers need).  launch_streamk_ordered therefore
-// only runs this kernel on request (f32_splitk 10) and under a StreamkTicket (mm_capi.hip), which checks the device and the stream and
-// orders the launch behind the previous one of its kind in this process; everything else takes the two-kernel teams form.  Visibility: the producer's stores, __syncthreads, one lane's agent-scope
-// release + s_waitcnt vmcnt(0) + relaxed agent store of the flag; the consumer's relaxed poll by one lane, agent-scope
-// acquire, __syncthreads, plain loads (MI355X_MICROARCH.md, inter-workgroup visibility: the valid forms).
+// Stream-K in TEAMS (what the shape-adaptive rule and f32_splitk = 0 run; 9 = the single-range form above, kept as an
+// independent cross-check).  Same idea of unit ranges, two changes.
 //
 // Teams.  With one range per workgroup, neighbouring workgroups sit at different k offsets of neighbouring tiles, so no two
 // of them ever want the same A or B slab at the same time: the XCD's L2 shares nothing and the launch becomes fabric-bound
@@ -854,31 +839,43 @@ __global__ __launch_bounds__(G::THREADS, G::MIN_WAVES) void mfma_f32_streamk_ker
 // super-tiles of sr x sc tiles, a team walks its range of (super-tile, slab) units with workgroup `lane` of the team on
 // tile `lane` of the super-tile, and all of a team are at the same slab at the same time -- each A slab is wanted by sc
 // of them and each B slab by sr.  Per lane this is exactly the scheme above with `teams` ranges.  Tiles of a ragged
-// super-tile that fall outside the matrix are skipped by their lane (the same lane in every team, so no flag is missed).
+// super-tile that fall outside the matrix are skipped by their lane (the same lane in every team).
 //
-// Combine::FixupKernel (f32_splitk 11; round 5's first answer, kept as the cross-check): the same teams, ranges and slots, but nobody waits -- the lowest-k part
-// of a cut tile goes to C, the other parts to their slots (plain stores, no flags), and streamk_teams_fixup_kernel below
-// adds the slots on top of C in the same ascending-k order.  Bit-identical to the hand-over form (the same additions in
-// the same order), residency-independent (no workgroup ever waits for another one), one more small kernel.
+// The combine.  Every segment of a tile other than its lowest-k one is the FIRST segment of the workgroup that owns it (a
+// range enters a tile from below only at its own start), and the lowest-k segment is the LAST thing its owner does.  A cut
+// tile is finished as C = part(t0) + part(t0 + 1) + ... in ascending k, a fixed order, no atomics on data, in one of two
+// ways that perform the same additions in the same order (bit-identical; tests compare them on every stream-K shape):
 //
-// Combine::LastArriver (round 5, what MM_PATH_AUTO runs): ONE kernel, and still nobody waits.  Every part of a cut tile --
-// the lowest-k one included -- goes to a scratch slot (agent-scope stores) and raises its flag; right after raising it, the
-// part's workgroup LOOKS at the flags of the tile's other parts (no loop): whoever finds them all raised is (one of) the
-// last to arrive and adds the slots in ascending k into C.  Raising and looking are ordered like a sequentially consistent
-// store and load (sc1 store, s_waitcnt vmcnt(0), sc1 loads: how this target implements seq_cst at agent scope), so of two
-// parts finishing at the same moment at least one sees the other; if both do, both write the same bits to C (the gather
-// reads slots only, never C: idempotent).  No workgroup ever depends on another one being resident, so the form is sound next
-// to anything else on the device; the additions and their order are those of the other two forms: bit-identical.  A
-// workgroup owns two slots and two flags: index 2w for its first segment (a higher part of some tile), 2w + 1 for its last
-// one (the lowest-k part of another tile).
-enum class Combine { FixupKernel, HandOver, LastArriver };
+// Combine::LastArriver (what MM_PATH_AUTO runs): ONE kernel in which nobody waits.  Every part of a cut tile -- the lowest-k
+// one included -- goes to a scratch slot (agent-scope stores: the reader may sit on another XCD) and raises its flag; right
+// after raising it, the part's workgroup LOOKS at the flags of the tile's other parts (no loop): whoever finds them all
+// raised is (one of) the last to arrive and adds the slots in ascending k into C.  Raising and looking are ordered like a
+// sequentially consistent store and load (sc1 store, s_waitcnt vmcnt(0), sc1 loads: how this target implements seq_cst at
+// agent scope), so of two parts finishing at the same moment at least one sees the other; if both do, both write the same
+// bits to C -- the gather reads slots only, never C, so it is idempotent (which is why the lowest-k part may NOT live in C:
+// a second gatherer would read the first one's sum).  No workgroup ever depends on another one being resident, so the form
+// is sound next to any other launch of any process, on CU-masked streams, on partitions and in graphs.  A workgroup owns
+// two slots and two flags: index 2w for its first segment (a higher part of some tile), 2w + 1 for its last one (the
+// lowest-k part of another tile).  A flag is raised when it holds the launch's epoch (flags_alloc, mm_capi.hip): nothing is
+// cleared between launches.  Visibility: slot stores sc1 + s_waitcnt vmcnt(0) + __syncthreads before the flag; on the
+// gathering side an agent-scope acquire (buffer_inv sc1) + __syncthreads before plain loads (MI355X_MICROARCH.md,
+// inter-workgroup visibility: the valid forms); tests/test_isa_contract.py pins the machine code.
+//
+// Combine::FixupKernel (f32_splitk 11, the cross-check): the lowest-k part of a cut tile goes to C, the other parts to their
+// slots (plain stores, no flags), and streamk_teams_fixup_kernel below adds the slots on top of C.  Two kernels, no
+// inter-workgroup communication at all; 0-3.5 % slower (profiles/r05f_*).
+//
+// (Rounds 3-4 ran a third form in which the owner of the lowest-k part WAITED inside the launch for the others' flags.  It
+// needed every workgroup of the launch -- and of every other launch of its kind, in any process -- to be resident at once,
+// which a library cannot guarantee; the last-arriver form is as fast without waiting, so the waiting form is retired:
+// HISTORY.md, round 5.)
+enum class Combine { FixupKernel, LastArriver };
 
 template <typename G, Combine MODE>
-__global__ __launch_bounds__(G::THREADS, G::MIN_WAVES) void mfma_f32_streamk_ordered_kernel(
+__global__ __launch_bounds__(G::THREADS, G::MIN_WAVES) void mfma_f32_streamk_teams_kernel(
     const float *__restrict__ A, const float *__restrict__ B, float *__restrict__ C, unsigned N, unsigned K, unsigned M,
     unsigned tiles_n, unsigned tiles_m, unsigned spt, unsigned sr, unsigned sc, unsigned teams_per_xcd, unsigned teams,
     float *__restrict__ slots, unsigned long long *__restrict__ flags, unsigned long long epoch) {
-  constexpr bool HANDOVER = MODE == Combine::HandOver, ARRIVE = MODE == Combine::LastArriver;
   __shared__ unsigned gather_here;   // LastArriver: thread 0's verdict for the workgroup
   const unsigned lanes = sr * sc, xcd = blockIdx.x % 8, place = blockIdx.x / 8;
   const unsigned team_in_xcd = place / lanes, lane = place % lanes;
@@ -897,7 +894,7 @@ __global__ __launch_bounds__(G::THREADS, G::MIN_WAVES) void mfma_f32_streamk_ord
     const float *a = A + kbeg, *b = B + (size_t)kbeg * M;
     if (s0 == 0 && s1 == spt) {
       tile_body<G, false>(a, b, C, N, klen, M, K, M, N, M, row0, col0);
-    } else if constexpr (ARRIVE) {
+    } else if constexpr (MODE == Combine::LastArriver) {
       // a part of a cut tile.  The tile's parts belong to teams t0 (lowest k: that team's LAST segment, slot / flag 2w' + 1)
       // and t0 + 1 .. t_end - 1 (their FIRST segments, slot / flag 2w'), same lane.
       const unsigned u_lo = st * spt, u_hi = u_lo + spt;
@@ -923,6 +920,7 @@ __global__ __launch_bounds__(G::THREADS, G::MIN_WAVES) void mfma_f32_streamk_ord
       }
       __syncthreads();
       if (gather_here) {   // (one of) the last to arrive: C = slot(t0) + slot(t0 + 1) + ... in ascending k, from slots only
+        // one slot at a time, all of a thread's quads in flight together: a slot costs one trip to memory, not QUADS of them
         constexpr int QUADS = G::BM * G::BN / 4 / G::THREADS;
         f32x4 acc[QUADS];
         const f32x4 *first = (const f32x4 *)(slots + (size_t)part_index(t0) * (G::BM * G::BN));
@@ -939,46 +937,12 @@ __global__ __launch_bounds__(G::THREADS, G::MIN_WAVES) void mfma_f32_streamk_ord
           if (row < N && col < M) *(f32x4 *)(C + (size_t)row * M + col) = acc[i];
         }
       }
-    } else if (s0 > 0) {   // not the lowest-k segment: this workgroup's first segment -> its slot, then the flag
+    } else if (s0 > 0) {   // FixupKernel, not the lowest-k segment: this workgroup's first segment -> its slot
       float *slot = slots + (size_t)w * (G::BM * G::BN);
       float *base = (float *)((unsigned long long)slot - ((unsigned long long)row0 * G::BN + col0) * sizeof(float));
-      tile_body<G, false, HANDOVER>(a, b, base, N, klen, M, K, G::BN, ~0u, ~0u, row0, col0);   // (hand-over: slot stores at agent scope)
-      if constexpr (HANDOVER) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every wavefront: its slot stores have reached the agent's coherence point
-        __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_store(flags + w, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // raised = holds this launch's epoch
-      }
-    } else if constexpr (MODE == Combine::FixupKernel) {   // the lowest-k segment of a split tile: into C; the fix-up kernel adds the others
+      tile_body<G, false>(a, b, base, N, klen, M, K, G::BN, ~0u, ~0u, row0, col0);
+    } else {               // FixupKernel, the lowest-k segment of a split tile: into C; the fix-up kernel adds the others
       tile_body<G, false>(a, b, C, N, klen, M, K, M, N, M, row0, col0);
-    } else {               // the lowest-k segment of a split tile: this one into C, then the others on top in ascending k
-      tile_body<G, false>(a, b, C, N, klen, M, K, M, N, M, row0, col0);
-      const unsigned u_hi = st * spt + spt;
-      unsigned t_end = team + 1;
-      while (t_end < teams && sk_range_begin(units, t_end, teams) < u_hi) ++t_end;   // ranges are never empty: teams <= units
-      if (threadIdx.x == 0) {
-        for (unsigned o = team + 1; o < t_end; ++o)
-          while (__hip_atomic_load(flags + o * lanes + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(8);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      }
-      __syncthreads();     // also: this workgroup's own stores to C are visible to all of its wavefronts
-      // one slot at a time, all of a thread's quads in flight together: a slot costs one trip to memory, not QUADS of them
-      constexpr int QUADS = G::BM * G::BN / 4 / G::THREADS;
-      f32x4 acc[QUADS];
-#pragma unroll
-      for (int i = 0; i < QUADS; ++i) {
-        const unsigned q = i * G::THREADS + threadIdx.x, row = row0 + q / (G::BN / 4), col = col0 + (q % (G::BN / 4)) * 4;
-        acc[i] = (row < N && col < M) ? *(const f32x4 *)(C + (size_t)row * M + col) : (f32x4)0.0f;
-      }
-      for (unsigned o = team + 1; o < t_end; ++o) {
-        const f32x4 *src = (const f32x4 *)(slots + (size_t)(o * lanes + lane) * (G::BM * G::BN));
-#pragma unroll
-        for (int i = 0; i < QUADS; ++i) acc[i] += src[i * G::THREADS + threadIdx.x];
-      }
-#pragma unroll
-      for (int i = 0; i < QUADS; ++i) {
-        const unsigned q = i * G::THREADS + threadIdx.x, row = row0 + q / (G::BN / 4), col = col0 + (q % (G::BN / 4)) * 4;
-        if (row < N && col < M) *(f32x4 *)(C + (size_t)row * M + col) = acc[i];
-      }
     }
     __syncthreads();
   }
@@ -997,7 +961,7 @@ static TeamShape streamk_team_shape(unsigned tiles_n, unsigned tiles_m) {
 // The second kernel of the two-kernel teams form: one workgroup per tile of C.  A tile that one team's range holds whole
 // was finished by the main kernel; for a cut tile C already holds the lowest-k part, and the slots of the teams that own
 // the other parts (the next teams in range order, same lane) are added on top in ascending k -- the additions of the
-// hand-over form's gather, in its order, by its thread mapping.
+// last-arriver form's gather, in its order, by its thread mapping.
 template <int BM, int BN, int THREADS>
 __global__ __launch_bounds__(THREADS) void streamk_teams_fixup_kernel(const float *__restrict__ slots, float *__restrict__ C, unsigned N,
                                                                        unsigned M, unsigned tiles_n, unsigned tiles_m, unsigned spt,
@@ -1045,20 +1009,20 @@ static TeamPlan streamk_team_plan(const Problem &p) {
   const unsigned long long super_tiles = (unsigned long long)(t.tiles_n / ts.sr) * (t.tiles_m / ts.sc), units = super_tiles * t.spt;
   // every place gets a team when there is work for it: a team's range is at least 8 slabs (below that the fill and drain
   // of the rings outweigh the slabs -- the chunk floor of split-K) and a tile is cut at most 8 ways (the gather is serial
-  // in the owner of the lowest part, and in the hand-over form a wait never aims further than 8 teams ahead)
+  // in whoever does it, and a part looks at no more than 7 siblings' flags)
   t.teams = (unsigned)std::max<unsigned long long>(1, std::min<unsigned long long>({8ull * t.teams_per_xcd, units / 8, 8 * super_tiles}));
   return t;
 }
 
 // The two-kernel teams form (f32_splitk 11; the cross-check of the default): teams, slots, and the fix-up kernel.  No
-// workgroup waits for another one either; the bits of the other two teams forms.
+// workgroup waits for another one either; the bits of the default form.
 template <typename G>
 int launch_streamk_teams(hipStream_t s, const Problem &p) {
   const TeamPlan t = streamk_team_plan<G>(p);
   const unsigned nwg = 512;
   static_assert(G::MIN_WAVES == 2, "two workgroups per CU: 64 places per XCD");
   static unsigned long long configured = 0;
-  if (int e = ensure_dynamic_lds((const void *)mfma_f32_streamk_ordered_kernel<G, Combine::FixupKernel>, G::LDS_BYTES, configured)) return e;
+  if (int e = ensure_dynamic_lds((const void *)mfma_f32_streamk_teams_kernel<G, Combine::FixupKernel>, G::LDS_BYTES, configured)) return e;
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return (int)e;
@@ -1071,7 +1035,7 @@ int launch_streamk_teams(hipStream_t s, const Problem &p) {
   if (tuning(TUNE_DEBUG_POISON) == 1 && ((e = hipMemsetAsync(slots, 0xFF, slot_bytes, s)) != hipSuccess ||
                                          (e = hipMemsetAsync(p.c, 0xFF, (size_t)p.n * p.m * sizeof(float), s)) != hipSuccess)) { (void)hipFreeAsync(slots, s); return (int)e; }
   (void)hipGetLastError();
-  hipLaunchKernelGGL((mfma_f32_streamk_ordered_kernel<G, Combine::FixupKernel>), dim3(nwg), dim3(G::THREADS), G::LDS_BYTES, s, (const float *)p.a,
+  hipLaunchKernelGGL((mfma_f32_streamk_teams_kernel<G, Combine::FixupKernel>), dim3(nwg), dim3(G::THREADS), G::LDS_BYTES, s, (const float *)p.a,
                      (const float *)p.b, (float *)p.c, p.n, p.k, p.m, t.tiles_n, t.tiles_m, t.spt, t.sr, t.sc, t.teams_per_xcd, t.teams,
                      slots, (unsigned long long *)nullptr, 0ull);
   int rc = (int)hipGetLastError();
@@ -1093,7 +1057,7 @@ int launch_streamk_arrive(hipStream_t s, const Problem &p) {
   const unsigned nwg = 512;
   static_assert(G::MIN_WAVES == 2, "two workgroups per CU: 64 places per XCD");
   static unsigned long long configured = 0;
-  if (int e = ensure_dynamic_lds((const void *)mfma_f32_streamk_ordered_kernel<G, Combine::LastArriver>, G::LDS_BYTES, configured)) return e;
+  if (int e = ensure_dynamic_lds((const void *)mfma_f32_streamk_teams_kernel<G, Combine::LastArriver>, G::LDS_BYTES, configured)) return e;
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return (int)e;
@@ -1109,56 +1073,12 @@ int launch_streamk_arrive(hipStream_t s, const Problem &p) {
   if (rc == 0) rc = flags_alloc(dev, s, (size_t)2 * nwg * sizeof(unsigned long long), &flags, &epoch);
   if (rc == 0) {
     (void)hipGetLastError();
-    hipLaunchKernelGGL((mfma_f32_streamk_ordered_kernel<G, Combine::LastArriver>), dim3(nwg), dim3(G::THREADS), G::LDS_BYTES, s,
+    hipLaunchKernelGGL((mfma_f32_streamk_teams_kernel<G, Combine::LastArriver>), dim3(nwg), dim3(G::THREADS), G::LDS_BYTES, s,
                        (const float *)p.a, (const float *)p.b, (float *)p.c, p.n, p.k, p.m, t.tiles_n, t.tiles_m, t.spt, t.sr, t.sc,
                        t.teams_per_xcd, t.teams, slots, (unsigned long long *)flags, epoch);
     rc = (int)hipGetLastError();
   }
   const hipError_t f1 = flags ? hipFreeAsync(flags, s) : hipSuccess, f2 = slots ? hipFreeAsync(slots, s) : hipSuccess;
-  return rc ? rc : f1 != hipSuccess ? (int)f1 : (int)f2;
-}
-
-// The hand-over form (f32_splitk 10, opt-in): one kernel, the gather overlapped with other teams' work.  Needs the whole
-// chip to itself among launches of its kind IN EVERY PROCESS that shares the device -- the library can only order the ones
-// of this process (StreamkTicket, mm_capi.hip) -- which is why MM_PATH_AUTO no longer takes it (VERDICT r4
-// next 5).  Where the ticket is refused it runs the form above: same bits.
-template <typename G>
-int launch_streamk_ordered(hipStream_t s, const Problem &p) {
-  const TeamPlan t = streamk_team_plan<G>(p);
-  const unsigned nwg = 512;
-  static_assert(G::MIN_WAVES == 2, "two workgroups per CU: 64 places per XCD");
-  static unsigned long long configured = 0;
-  if (int e = ensure_dynamic_lds((const void *)mfma_f32_streamk_ordered_kernel<G, Combine::HandOver>, G::LDS_BYTES, configured)) return e;
-  int dev = 0;
-  hipError_t e = hipGetDevice(&dev);
-  if (e != hipSuccess) return (int)e;
-  hipMemPool_t pool = nullptr;
-  if (int rc = workspace_pool(dev, &pool)) return rc;
-  // scratch first, the ticket last: only wait-for-previous, launch and record-behind-it happen while it is held
-  float *slots = nullptr;
-  void *flags = nullptr;
-  unsigned long long epoch = 0;
-  const size_t slot_bytes = (size_t)nwg * G::BM * G::BN * sizeof(float);
-  int rc = (int)hipMallocFromPoolAsync((void **)&slots, slot_bytes, pool, s);
-  if (rc == 0 && tuning(TUNE_DEBUG_POISON) == 1) rc = (int)hipMemsetAsync(slots, 0xFF, slot_bytes, s);   // debug_poison: NaN in every slot ...
-  if (rc == 0 && tuning(TUNE_DEBUG_POISON) == 1) rc = (int)hipMemsetAsync(p.c, 0xFF, (size_t)p.n * p.m * sizeof(float), s);   // ... and in C (pure output): an unfinished tile shows
-  if (rc == 0) rc = flags_alloc(dev, s, nwg * sizeof(unsigned long long), &flags, &epoch);
-  bool refused = false;
-  if (rc == 0) {
-    StreamkTicket ticket(dev, s);      // the whole chip, an unmasked stream, no capture, ordered behind the previous launch of this kind
-    rc = ticket.error();
-    refused = rc == 0 && !ticket.admitted();
-    if (rc == 0 && ticket.admitted()) {
-      (void)hipGetLastError();
-      hipLaunchKernelGGL((mfma_f32_streamk_ordered_kernel<G, Combine::HandOver>), dim3(nwg), dim3(G::THREADS), G::LDS_BYTES, s, (const float *)p.a,
-                         (const float *)p.b, (float *)p.c, p.n, p.k, p.m, t.tiles_n, t.tiles_m, t.spt, t.sr, t.sc, t.teams_per_xcd, t.teams,
-                         slots, (unsigned long long *)flags, epoch);
-      rc = (int)hipGetLastError();
-      if (rc == 0) ticket.launched();
-    }
-  }   // ~StreamkTicket: records the event the next launch of this kind waits on, hands the ticket back
-  const hipError_t f1 = flags ? hipFreeAsync(flags, s) : hipSuccess, f2 = slots ? hipFreeAsync(slots, s) : hipSuccess;
-  if (rc == 0 && refused) return launch_streamk_arrive<G>(s, p);
   return rc ? rc : f1 != hipSuccess ? (int)f1 : (int)f2;
 }
 
@@ -1317,7 +1237,7 @@ int mfma_f32_variant_id(int index) { return index >= 0 && index < mfma_f32_num_v
 // relative efficiency.
 static const TileCandidate kAutoCands[] = {{33, 128, 256, 2, 1.00}, {8, 256, 256, 1, 0.991}, {35, 128, 128, 2, 0.993}};
 
-// Stream-K (launch_streamk_ordered) against the best whole-tile launch, in pick_tile's units (tile area x workgroups the
+// Stream-K (launch_streamk_arrive) against the best whole-tile launch, in pick_tile's units (tile area x workgroups the
 // busiest CU runs one after the other; a full round of 512 tiles of 128 x 128 = 2).  Fitted to
 // profiles/r03w_f32_streamk_ordered_sweep.txt (2176^3 ... 9216^3): the persistent workgroups run at the whole-tile
 // kernel's rate, plus a quarter of a tile for the launch's one-off parts that the whole tiles of a multi-round launch hide
@@ -1514,7 +1434,7 @@ int mfma_f32_resolve(const Problem &p, int variant) {
 // side by side and a second kernel adds the S partial planes in ascending order -- deterministic, run to run and
 // whatever the placement, but a different summation order than the unsplit kernel (as accurate or better: shorter
 // chains).  f32_splitk: -1 this rule (and stream-K by streamk_wins), 0 stream-K (teams; the last part to arrive gathers), 1 neither, 2..8 that many chunks, 9 stream-K in
-// single ranges with its fix-up kernel (cross-check), 10 / 11 the teams form with the waiting hand-over (opt-in) / with a fix-up kernel (cross-check): the bits of 0 (always only
+// single ranges with its fix-up kernel (cross-check), 11 the teams form with a fix-up kernel (cross-check): the bits of 0 (always only
 // for row-major A and variant 35).  Row slabs of a bigger job (Problem::n_total) never take stream-K: its unit ranges would
 // depend on the slab, and with them a row's summation order.
 int mfma_f32_splitk(const Problem &p, int variant) {
@@ -1528,7 +1448,7 @@ int mfma_f32_splitk(const Problem &p, int variant) {
   if (variant != 35) return 1;
   const int knob = tuning(TUNE_F32_SPLITK);
   const unsigned long long sk_units = (unsigned long long)((p.n + 127) / 128) * ((p.m + 127) / 128) * (p.k / 32);   // the kernels count units in 32 bits
-  if (knob == 0 || knob == 9 || knob == 10 || knob == 11) return (p.k % 32 == 0 && p.k >= 64 && sk_units < (1ull << 31)) ? knob : 1;   // stream-K forced: 0 = teams, last arriver gathers (the one auto takes), 11 = teams + fix-up kernel, 10 = teams with the waiting hand-over (opt-in), 9 = single ranges + fix-up kernel
+  if (knob == 0 || knob == 9 || knob == 11) return (p.k % 32 == 0 && p.k >= 64 && sk_units < (1ull << 31)) ? knob : 1;   // stream-K forced: 0 = teams, last arriver gathers (the one auto takes), 11 = teams + fix-up kernel, 9 = single ranges + fix-up kernel
   const unsigned rows = p.n_total ? p.n_total : p.n;   // of the whole job (Problem::n_total)
   const unsigned long long tiles = (unsigned long long)((rows + 127) / 128) * ((p.m + 127) / 128);
   unsigned s;
@@ -1589,7 +1509,6 @@ int launch_mfma_f32(hipStream_t s, const Problem &p, int variant) {
       const int splits = mfma_f32_splitk(p, v);
       if (splits == 0) return sdma_fits(p, 32) ? launch_streamk_arrive<T128x128>(s, p) : launch_streamk_arrive<T128x128v>(s, p);
       if (splits == 11) return sdma_fits(p, 32) ? launch_streamk_teams<T128x128>(s, p) : launch_streamk_teams<T128x128v>(s, p);
-      if (splits == 10) return sdma_fits(p, 32) ? launch_streamk_ordered<T128x128>(s, p) : launch_streamk_ordered<T128x128v>(s, p);
       if (splits == 9) return sdma_fits(p, 32) ? launch_streamk<T128x128>(s, p) : launch_streamk<T128x128v>(s, p);
       return sdma_fits(p, 32) ? launch_geo<T128x128>(s, p, (unsigned)splits) : launch_geo<T128x128v>(s, p, (unsigned)splits);
     }

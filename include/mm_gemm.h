@@ -226,14 +226,8 @@ int mm_kernel_info(const mm_config_t *cfg, unsigned size_n, unsigned size_k, uns
  * 0 stream-K as MM_PATH_AUTO runs it: teams of workgroups, every part of a tile that a range boundary cuts goes to a scratch
  * slot and raises a flag, and the LAST part to arrive adds the slots in ascending k into C -- one kernel in which no workgroup
  * ever waits for another one, so it is sound next to anything else on the device (other streams, other processes), on
- * CU-masked streams, on partitions and in graphs; 11 the same with a small fix-up kernel doing the gather (cross-check), 10
- * the same with the owner of the lowest-k part WAITING for the others' flags inside the launch (opt-in) -- 0, 10 and 11 give
- * the same bits; 9 stream-K in single ranges with its own fix-up kernel (cross-check, its own bits).  Form 10 has workgroups
- * wait for each other inside one launch; the library runs it only where that is sound as far as it can see -- a device
- * reporting 256 compute units, a stream without a CU mask, not under stream capture, never two such launches of THIS
- * PROCESS at once (each is ordered behind the previous one on the device with an event) -- and runs form 0 otherwise.  It
- * cannot see other processes: whoever sets f32_splitk = 10 vouches that no second process runs such launches on the same
- * device (two of them could each hold half the chip and wait for ever).
+ * CU-masked streams, on partitions and in graphs; 11 the same with a small fix-up kernel doing the gather (cross-check, the
+ * bits of 0); 9 stream-K in single ranges with its own fix-up kernel (cross-check, its own bits).
  * "debug_poison" = 1 fills the scratch that kernels hand partial tiles through, and C itself (pure output), with NaN before
  * every stream-K launch: a read of anything the launch did not write, or a tile nobody finished, then shows in C (tests only).  "md_virtual_devices": see mm_gemm_multi_device.  Any
  * other id is refused: the retired schedules and the work-skipping ablations of the measurement history exist only in the

@@ -61,7 +61,7 @@ _TIERS = [
     (2, ("tests/test_gpu_ref_hosts.py", "tests/test_run_hardware_cli.py", "tests/test_gpu_benchmark_driver.py")),
     (3, ("test_multi_device_", "tests/test_gpu_capi.py")),
     # tier 5 (default): the rest of the parity matrix
-    # tier 7: shape-dispatch stress, hand-over stress, fuzz, soak
+    # tier 7: shape-dispatch stress, stream-K stress, fuzz, soak
     (7, ("test_f32_small_problems_take_the_64x64", "test_f32_64x64_geometry_", "test_f32_split_k_for_small_problems",
          "test_f32_stream_k_", "tests/test_gpu_fuzz.py", "test_race_screen_", "tests/test_gpu_streamk_stress.py")),
     # tier 9: self-imposed guards

@@ -223,11 +223,12 @@ def test_f32_split_k_for_small_problems_is_deterministic_and_accurate(shape, spl
 def test_f32_stream_k_for_partial_rounds_is_deterministic_and_accurate(shape, forced):
     """Problems of a few partial rounds of 128 x 128 tiles are dealt out to 512 persistent workgroups in equal ranges of
     (tile, slab) units -- to teams of up to 4 x 4 workgroups on neighbouring tiles, so that an XCD's L2 still shares the
-    slabs.  A tile cut by a range boundary is finished in ascending k from scratch slots, in three interchangeable ways:
+    slabs.  A tile cut by a range boundary is finished in ascending k from scratch slots, in two interchangeable ways:
     the LAST PART TO ARRIVE gathers (what MM_PATH_AUTO runs, f32_splitk 0: one kernel, every part raises a flag and then
-    looks at the others' -- nobody waits); a small second kernel gathers (11); the owner of the lowest-k part WAITS for the
-    others' flags and gathers (10, opt-in).  All three perform the same additions in the same order: BIT-IDENTICAL.  Same
-    bits on every launch; inside the fp32 bound; picked by the shape-adaptive rule where it pays (`auto` cases) and
+    looks at the others' -- nobody waits), or a small second kernel gathers (11, the cross-check).  Both perform the same
+    additions in the same order: BIT-IDENTICAL.  (Rounds 3-4's form, in which the owner of the lowest-k part waited for the
+    others inside the launch, is retired: it gave these bits too, was no faster, and could not be made safe next to other
+    processes.)  Same bits on every launch; inside the fp32 bound; picked by the shape-adaptive rule where it pays (`auto` cases) and
     forcible (ragged N / M, K of 3 slabs, ranges shorter than a tile, one tile cut 512 ways).  f32_splitk = 9 is the
     single-range form with its own fix-up kernel: an independent implementation of the same idea (different cut points,
     different bits)."""
@@ -244,9 +245,6 @@ def test_f32_stream_k_for_partial_rounds_is_deterministic_and_accurate(shape, fo
         name = g.kernel_name(g.make_config("float"), n, k, m)
         runs = [g.matmul_capi(a, b)[0] for _ in range(3)]
         g.set_tuning("f32_variant", 35)
-        g.set_tuning("f32_splitk", 10)
-        name_handover = g.kernel_name(g.make_config("float"), n, k, m)
-        c_handover = [g.matmul_capi(a, b)[0] for _ in range(2)]
         g.set_tuning("f32_splitk", 11)
         name_two = g.kernel_name(g.make_config("float"), n, k, m)
         c_two = [g.matmul_capi(a, b)[0] for _ in range(2)]
@@ -259,12 +257,10 @@ def test_f32_stream_k_for_partial_rounds_is_deterministic_and_accurate(shape, fo
         g.set_tuning("f32_splitk", -1)
         g.set_tuning("f32_variant", -1)
     assert name == "mfma_f32_128x128x32_w4x2_streamk", name
-    assert name_handover == "mfma_f32_128x128x32_w4x2_streamk_handover", name_handover
     assert name_fixup == "mfma_f32_128x128x32_w4x2_streamk_fixup", name_fixup
     c1 = runs[0]
     assert np.array_equal(c1, runs[1]) and np.array_equal(c1, runs[2])
     assert name_two == "mfma_f32_128x128x32_w4x2_streamk_two_kernels", name_two
-    assert np.array_equal(c1, c_handover[0]) and np.array_equal(c1, c_handover[1]), "last-arriver form != hand-over form"
     assert np.array_equal(c1, c_two[0]) and np.array_equal(c1, c_two[1]), "last-arriver form != two-kernel form"
     # the bar first (BASELINE.json north_star, applied normwise on this mixed-sign data) ...
     for what, c in (("teams + fix-up", c1), ("single ranges + fix-up", c_fixup), ("unsplit", c_one)):
@@ -278,7 +274,7 @@ def test_f32_stream_k_for_partial_rounds_is_deterministic_and_accurate(shape, fo
 
 
 def test_f32_stream_k_flags_need_no_clearing_between_launches_and_survive_a_release():
-    """The hand-over flags hold the launch's epoch (a process-wide 64-bit count) in memory that never holds anything else, so
+    """The stream-K flags hold the launch's epoch (a process-wide 64-bit count) in memory that never holds anything else, so
     a launch does not clear them: back-to-back launches of different shapes reuse the same block, mm_release_workspace hands
     it back to the driver and the next launch clears its fresh block once.  Same bits throughout."""
     import torch
@@ -290,10 +286,8 @@ def test_f32_stream_k_flags_need_no_clearing_between_launches_and_survive_a_rele
         b = torch.empty((k, m), device=dev).uniform_(-3, 10, generator=torch.Generator(device=dev).manual_seed(30 + i))
         assert g.kernel_name(g.make_config("float"), n, k, m).endswith("streamk")
         ops.append((a, b))
-        alone.append(g.matmul(a, b).clone())        # the last-arriver form MM_PATH_AUTO runs (epoch flags too): the hand-over form must give its bits
+        alone.append(g.matmul(a, b).clone())        # the last-arriver form MM_PATH_AUTO runs: the one with flags
     torch.cuda.synchronize()
-    g.set_tuning("f32_variant", 35)
-    g.set_tuning("f32_splitk", 10)                  # the opt-in hand-over form: the one with flags
     try:
         for round_ in range(3):
             for rep in range(20):
@@ -306,14 +300,12 @@ def test_f32_stream_k_flags_need_no_clearing_between_launches_and_survive_a_rele
         g.set_tuning("f32_splitk", -1)
 
 
-@pytest.mark.parametrize("form", ["default", "handover"])
+@pytest.mark.parametrize("form", ["default", "two_kernel"])
 def test_f32_stream_k_launches_sharing_the_chip_make_progress_and_keep_their_bits(form):
     """Two stream-K launches on two streams, plus a third stream of whole-tile launches, compete for the same CUs, so
-    neither has all of its workgroups resident.  default (what MM_PATH_AUTO runs): the last part to arrive gathers, nobody
-    waits inside a kernel -- parts of one tile finish in any order, under any residency.  handover (f32_splitk 10, opt-in):
-    a workgroup waits on flags of workgroups with higher ids, and the library orders such launches one behind the other
-    (StreamkTicket): each must still finish and give the bits it gives alone.  Run under a watchdog: a hang here would
-    otherwise take the box down with it."""
+    neither has all of its workgroups resident.  The last part of a cut tile to arrive gathers it and nobody waits inside a
+    kernel, so parts of one tile may finish in any order, under any residency: each launch must finish and give the bits it
+    gives alone (default; two_kernel = the fix-up-kernel cross-check, f32_splitk 11).  Run under a watchdog all the same."""
     import torch
     dev = torch.device("cuda:0")
     shapes = [(2341, 2304, 2304), (3584, 512, 3584), (2048, 2048, 2048)]
@@ -331,9 +323,9 @@ def test_f32_stream_k_launches_sharing_the_chip_make_progress_and_keep_their_bit
     try:
         for rep in range(25):
             for i, (a, b) in enumerate(ops):
-                stream_k = form == "handover" and names[i].endswith("streamk")
+                stream_k = form == "two_kernel" and names[i].endswith("streamk")
                 g.set_tuning("f32_variant", 35 if stream_k else -1)      # (read when the launch is enqueued)
-                g.set_tuning("f32_splitk", 10 if stream_k else -1)
+                g.set_tuning("f32_splitk", 11 if stream_k else -1)
                 with torch.cuda.stream(streams[i]):
                     outs[i].append(g.matmul(a, b))
     finally:

@@ -1,23 +1,26 @@
-"""The machine code of the hand-synchronised stream-K kernel (gemm_hls_amd/csrc/mm_mfma_f32.hip:
-mfma_f32_streamk_ordered_kernel<G, HANDOVER = true>, the opt-in one-kernel form, f32_splitk 10), checked on the gfx950 ISA
-hipcc emits for the shipped source with the build's flags -- and of its HANDOVER = false twin, the form MM_PATH_AUTO runs,
-which must contain NO inter-workgroup synchronisation at all (no flag store, no poll, no sleep, no invalidate).
+"""The machine code of the stream-K kernel (gemm_hls_amd/csrc/mm_mfma_f32.hip: mfma_f32_streamk_teams_kernel), checked on the gfx950
+ISA hipcc emits for the shipped source with the build's flags.
 
-The kernel hands partial tiles from one workgroup to another INSIDE a launch through scratch slots and epoch flags, with
-hand-written agent-scope (sc1) stores.  Its memory ordering is a contract between the source (inline asm included) and
-the compiler; a compiler bump or an innocent-looking edit can break it silently -- results would still be right most
-of the time.  This test pins what a reviewer checks by hand:
+In the form MM_PATH_AUTO runs (Combine::LastArriver) the parts of a tile that a range boundary cuts go to scratch slots, each
+part raises an epoch flag and then LOOKS at its siblings' flags, and the last to arrive adds the slots into C -- across XCDs,
+with hand-written agent-scope (sc1) stores.  Nobody waits; but who gathers, and whether the gatherer sees the slots, is a
+contract between the source (inline asm included) and the compiler: a compiler bump or an innocent-looking edit can break it
+silently -- results would still be right most of the time.  This test pins what a reviewer checks by hand:
 
-  producer  every slot store is `global_store_dwordx4 ... sc1` and is followed by a wait state (`s_nop`): a store of more
-            than 8 bytes reads its data registers late, the next VALU write to them would otherwise be stored instead;
-            then `s_waitcnt vmcnt(0)` (each wavefront: its slot stores have reached the coherence point), `s_barrier`
-            (all wavefronts have), and only then ONE lane's `global_store_dwordx2 ... sc1` of the flag -- no other store
-            in between;
-  consumer  the poll is an sc1 load (never served from this CU's non-coherent lines) in a loop with `s_sleep`; after it
-            `s_waitcnt vmcnt(0)`, `buffer_inv sc1` (drop stale lines before the slots are read), `s_barrier` (the other
-            wavefronts do not start early), and only then the gather's `global_load_dwordx4`;
-  data      no atomics on data anywhere: the order of additions is fixed (kernel/Compute.cpp:108-142: one deterministic
-            k-ordered result per element).
+  every part   slot stores are `global_store_dwordx4 ... sc1`, each followed by a wait state (`s_nop`: a store of more than 8 bytes
+               reads its data registers late, the next VALU write to them would otherwise be stored instead); then
+               `s_waitcnt vmcnt(0)` (each wavefront: its slot stores have reached the coherence point), `s_barrier` (all
+               wavefronts have), and only then ONE lane's `global_store_dwordx2 ... sc1` of the flag -- no other store in between;
+  raise, look  `s_waitcnt vmcnt(0)` between the flag store and the first sibling-flag load, the loads `sc1`: the store-then-load
+               order of a sequentially consistent pair on this target, without which two parts finishing together could both
+               miss each other and nobody would gather;
+  gather       `buffer_inv sc1` (drop stale lines before the slots are read) after the looks, `s_barrier` (the other wavefronts do
+               not start early), and only then the gather's `global_load_dwordx4`;
+  wait-free    no `s_sleep`, no atomics on data (the order of additions is fixed: kernel/Compute.cpp:108-142, one deterministic
+               k-ordered result per element), no whole-L2 write-back.
+
+The cross-check form (Combine::FixupKernel + streamk_teams_fixup_kernel, f32_splitk 11) must contain no inter-workgroup
+communication at all; and no kernel of the translation unit may spill.
 
 CPU test: hipcc cross-compiles the translation unit to assembly here (about 15 s)."""
 import os
@@ -55,23 +58,18 @@ def ordered_kernels():
         if "s_endpgm" in t:
             kernels[name] = body
             name = None
-    picked = {k: v for k, v in kernels.items() if "mfma_f32_streamk_ordered_kernel" in k}
-    assert len(picked) == 6, list(kernels)           # (scalar-base DMA, vector-address) x Combine::{FixupKernel, HandOver, LastArriver}
+    picked = {k: v for k, v in kernels.items() if "mfma_f32_streamk_teams_kernel" in k}
+    assert len(picked) == 4, list(kernels)           # (scalar-base DMA, vector-address) x Combine::{FixupKernel, LastArriver}
     _ALL["kernels"] = kernels
     _ALL["metadata"] = r.stdout
-    handover = _by_combine(1)
-    return handover
+    return _by_combine(1)
 
 
 def _by_combine(value):
-    """The two instantiations (DMA forms) of mfma_f32_streamk_ordered_kernel<G, Combine(value)>: 0 FixupKernel, 1 HandOver, 2 LastArriver."""
-    picked = {k: v for k, v in _ALL["kernels"].items() if "mfma_f32_streamk_ordered_kernel" in k and f"CombineE{value}EEEv" in k}
-    assert len(picked) == 2, [k for k in _ALL["kernels"] if "streamk_ordered" in k]
+    """The two instantiations (DMA forms) of mfma_f32_streamk_teams_kernel<G, Combine(value)>: 0 FixupKernel, 1 LastArriver."""
+    picked = {k: v for k, v in _ALL["kernels"].items() if "mfma_f32_streamk_teams_kernel" in k and f"CombineE{value}EEEv" in k}
+    assert len(picked) == 2, [k for k in _ALL["kernels"] if "streamk_teams" in k]
     return picked
-
-
-def _two_kernel_forms(ordered_kernels):
-    return _by_combine(0)
 
 
 def _is(op, ins):
@@ -86,46 +84,16 @@ def test_slot_stores_are_agent_scope_and_followed_by_a_wait_state(ordered_kernel
             assert _is("s_nop", body[i + 1]), (name, body[i], body[i + 1])
 
 
-def test_flag_is_raised_by_one_sc1_store_after_waitcnt_and_barrier(ordered_kernels):
-    for name, body in ordered_kernels.items():
-        flag = [i for i, t in enumerate(body) if _is("global_store_dwordx2", t)]
-        assert len(flag) == 1 and body[flag[0]].endswith("sc1"), (name, [body[i] for i in flag])
-        i = flag[0]
-        back = body[max(0, i - 40):i]
-        bar = max(j for j, t in enumerate(back) if _is("s_barrier", t))          # the barrier in front of the flag store
-        assert not any(t.startswith("global_store") or t.startswith("buffer_store") for t in back[bar:]), (name, back[bar:])
-        waits = [j for j, t in enumerate(back[:bar]) if _is("s_waitcnt", t) and "vmcnt(0)" in t]
-        assert waits, (name, back)
-        # nothing that stores between that waitcnt and the barrier either
-        assert not any(t.startswith("global_store") for t in back[waits[-1]:bar]), (name, back[waits[-1]:bar])
-
-
-def test_poll_is_an_sc1_load_and_the_gather_waits_for_invalidate_and_barrier(ordered_kernels):
-    for name, body in ordered_kernels.items():
-        polls = [i for i, t in enumerate(body) if _is("global_load_dwordx2", t) and t.endswith("sc1")]
-        assert len(polls) >= 1, name
-        assert all(t.endswith("sc1") for t in body if _is("global_load_dwordx2", t)), name     # no plain 8-byte load could be the poll
-        assert any(_is("s_sleep", t) for t in body), name
-        inv = [i for i, t in enumerate(body) if t == "buffer_inv sc1"]
-        assert len(inv) == 1, (name, inv)
-        i = inv[0]
-        assert _is("s_waitcnt", body[i - 1]) and "vmcnt(0)" in body[i - 1], (name, body[i - 1])
-        after = body[i + 1:]
-        first_barrier = next(j for j, t in enumerate(after) if _is("s_barrier", t))
-        first_gather = next(j for j, t in enumerate(after) if _is("global_load_dwordx4", t))
-        assert first_barrier < first_gather, (name, first_barrier, first_gather)
-
-
 def test_no_atomics_on_data_and_no_whole_cache_write_back(ordered_kernels):
     for name, body in ordered_kernels.items():
         assert not any("atomic" in t for t in body), name
         assert not any(_is("buffer_wbl2", t) for t in body), name      # slots go out with sc1 stores, not by writing the L2 back
 
 
-def test_the_default_stream_k_form_has_no_inter_workgroup_synchronisation(ordered_kernels):
-    """mfma_f32_streamk_ordered_kernel<G, false> + streamk_teams_fixup_kernel is what MM_PATH_AUTO runs:
-    no workgroup may wait for another one -- no flag store, no polling load, no sleep, no invalidate, no agent-scope store."""
-    for name, body in _two_kernel_forms(ordered_kernels).items():
+def test_the_two_kernel_cross_check_form_has_no_inter_workgroup_communication(ordered_kernels):
+    """mfma_f32_streamk_teams_kernel<G, Combine::FixupKernel> + streamk_teams_fixup_kernel (f32_splitk 11, the cross-check of the
+    default): no inter-workgroup communication at all -- no flag store, no flag load, no sleep, no invalidate, no agent-scope store."""
+    for name, body in _by_combine(0).items():
         assert not any(_is("global_store_dwordx2", t) for t in body), name
         assert not any(_is("global_load_dwordx2", t) and t.endswith("sc1") for t in body), name
         assert not any(_is("s_sleep", t) for t in body), name
@@ -146,12 +114,12 @@ def test_no_shipped_matrix_core_kernel_of_this_unit_spills(ordered_kernels):
 
 
 def test_the_last_arriver_form_is_wait_free_and_orders_raise_before_look(ordered_kernels):
-    """mfma_f32_streamk_ordered_kernel<G, Combine::LastArriver>, what MM_PATH_AUTO runs: every part stores its slot at agent scope
+    """mfma_f32_streamk_teams_kernel<G, Combine::LastArriver>, what MM_PATH_AUTO runs: every part stores its slot at agent scope
     (sc1 + wait state), then s_waitcnt vmcnt(0) -> s_barrier -> ONE sc1 flag store -> s_waitcnt vmcnt(0) -> sc1 flag LOADS (the
     store-then-load order of a sequentially consistent pair on this target) -> buffer_inv sc1 -> s_barrier -> the gather's loads.
     And it never waits: no s_sleep, and no flag load sits in a loop that polls (the only backward branches after the flag store
     are the loop over the tile's parts and the segment loop, both of which advance)."""
-    for name, body in _by_combine(2).items():
+    for name, body in _by_combine(1).items():
         slot_stores = [i for i, t in enumerate(body) if _is("global_store_dwordx4", t) and t.endswith("sc1")]
         assert len(slot_stores) >= 16, (name, len(slot_stores))
         for i in slot_stores:

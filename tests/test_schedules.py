@@ -329,7 +329,7 @@ def test_streamk_ranges_random_configurations():
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-# Stream-K in teams (mfma_f32_streamk_ordered_kernel in its three Combine forms: hand-over, fix-up kernel, last arriver), replayed
+# Stream-K in teams (mfma_f32_streamk_teams_kernel: the last arriver gathers, or a fix-up kernel does), replayed
 # with the kernel's integer formulas: teams of sr x sc workgroups walk equal ranges of (super-tile, slab) units; a segment
 # that does not begin a tile is its workgroup's FIRST one (-> slot + flag), a segment that begins a tile but does not end it
 # is its workgroup's LAST one (-> C, then waits for and adds the slots of the following teams' same lane).  Checked: every

@@ -32,16 +32,16 @@ for i in range(args.shapes):
     assert err < 6e-6, ("error", err, (n, k, m), name)
     worst = max(worst, err)
     met[name.replace("mfma_f32_", "")] += 1
-    if name.endswith("_streamk"):      # the opt-in hand-over form (f32_splitk 10) performs the same additions in the same order: same bits
+    if name.endswith("_streamk"):      # the two-kernel cross-check (f32_splitk 11) performs the same additions in the same order: same bits
         g.set_tuning("f32_variant", 35)
         try:
-            for knob, tag in ((10, "_streamk_handover"), (11, "_streamk_two_kernels")):
+            for knob, tag in ((11, "_streamk_two_kernels"),):
                 g.set_tuning("f32_splitk", knob)
                 assert g.kernel_name(g.make_config("float"), n, k, m).endswith(tag)
                 assert torch.equal(g.matmul(a, b), c1), (tag + " != the default (last-arriver) form", (n, k, m))
         finally:
             g.set_tuning("f32_variant", -1); g.set_tuning("f32_splitk", -1)
-        met["(hand-over form == two-kernel form == default form)"] += 1
+        met["(two-kernel form == default form)"] += 1
     if n % 4 == 0:
         at = a.t().contiguous()
         name_t = g.kernel_name(g.make_config("float", transposed_a=True), n, k, m)

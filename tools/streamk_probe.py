@@ -1,5 +1,5 @@
-"""Stream-K probe: correctness of the combine forms (f32_splitk 0 = teams + fix-up kernel, 10 = teams with the hand-over inside the
-launch, 9 = single ranges + fix-up kernel)
+"""Stream-K probe: correctness of the combine forms (f32_splitk 0 = teams, the last arriver gathers, 11 = teams + fix-up kernel,
+9 = single ranges + fix-up kernel)
 against float64 on ragged shapes, run-to-run bit identity, and their rates next to the whole-tile kernels."""
 import sys, numpy as np
 sys.path.insert(0, "tools"); from _lib import g
@@ -12,7 +12,7 @@ for (n, k, m) in [(1024, 1024, 1024), (300, 2048, 272), (640, 512, 384), (2560, 
     exact = a.astype(np.float64) @ b.astype(np.float64)
     g.set_tuning("f32_variant", 35); g.set_tuning("f32_splitk", 1)
     c0, _ = g.matmul_capi(a, b)
-    for knob in (0, 10, 9):
+    for knob in (0, 11, 9):
         g.set_tuning("f32_splitk", knob)
         name = g.kernel_name(g.make_config("float"), n, k, m)
         cs = [g.matmul_capi(a, b)[0] for _ in range(4)]

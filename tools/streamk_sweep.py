@@ -1,5 +1,5 @@
-"""Stream-K rate sweep: shape-adaptive pick / whole tiles only / teams + fix-up kernel (f32_splitk 0, what auto runs) / teams with
-the hand-over inside the launch (10, opt-in) / single ranges + fix-up kernel (9)."""
+"""Stream-K rate sweep: shape-adaptive pick / whole tiles only / teams, the last arriver gathers (f32_splitk 0, what auto runs) /
+teams + fix-up kernel (11) / single ranges + fix-up kernel (9)."""
 import sys
 sys.path.insert(0, "tools"); from _lib import g
 import sweep
@@ -14,4 +14,4 @@ def rate(s, sk, var):
 for s in sizes:
     t = (s + 127) // 128
     name = g.kernel_name(g.make_config("float"), s, s, s)
-    print(s, f"{t}x{t} tiles: auto", rate(s, -1, -1), "whole tiles", rate(s, 1, -1), "stream-K last-arriver", rate(s, 0, 35), "teams+fixup", rate(s, 11, 35), "hand-over", rate(s, 10, 35), "single-range fix-up", rate(s, 9, 35), " auto =", name, flush=True)
+    print(s, f"{t}x{t} tiles: auto", rate(s, -1, -1), "whole tiles", rate(s, 1, -1), "stream-K last-arriver", rate(s, 0, 35), "teams+fixup", rate(s, 11, 35), "single-range fix-up", rate(s, 9, 35), " auto =", name, flush=True)
