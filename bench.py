@@ -180,7 +180,11 @@ LIVE = {
 LIVE_KERNEL = LIVE["float"][0]
 
 
-def live_counters(kernel_name, shape, avg_launch_ms, key="float", timeout=240):
+LIVE_STATE = {"deadline": None, "dead": False}   # one wall-clock budget for ALL counter passes of a run; the first failure ends them
+LIVE_BUDGET_S = 150.0
+
+
+def live_counters(kernel_name, shape, avg_launch_ms, key="float", timeout=75):
     """rocprofv3 child passes on the same shape after the timed legs (they serialise and slow the kernel): FETCH_SIZE, WRITE_SIZE in
     separate --pmc passes (gfx950 correction: fetch doubled, MI355X_MICROARCH.md HBM section) and, for the matrix-core kernels,
     SQ_VALU_MFMA_BUSY_CYCLES + GRBM_GUI_ACTIVE -- each with --kernel-trace only.  Returns None when rocprofv3 is absent, the kernel
@@ -192,6 +196,10 @@ def live_counters(kernel_name, shape, avg_launch_ms, key="float", timeout=240):
     if (os.environ.get("MM_BENCH_NO_PMC") or shutil.which("rocprofv3") is None or kernel_name != want or list(shape) != [size] * 3
             or size != WORKLOADS[key][3]):
         return None
+    if LIVE_STATE["dead"]:
+        return None
+    if LIVE_STATE["deadline"] is None:
+        LIVE_STATE["deadline"] = time.perf_counter() + LIVE_BUDGET_S
     workdir = tempfile.mkdtemp(prefix="mm_bench_pmc_", dir="/tmp")
     try:
         import csv
@@ -199,11 +207,14 @@ def live_counters(kernel_name, shape, avg_launch_ms, key="float", timeout=240):
         import subprocess
 
         def one_pass(counters, tag):
+            left = LIVE_STATE["deadline"] - time.perf_counter()
+            if left < 10.0:
+                raise RuntimeError("the run's budget for counter passes is used up")
             d = os.path.join(workdir, tag)
             os.makedirs(d, exist_ok=True)
             cmd = ["rocprofv3", "--pmc", *counters, "--kernel-trace", "-d", d, "-o", "pmc", "--output-format", "csv", "--",
                    sys.executable, os.path.join(ROOT, "tools", "sweep.py"), sweep_args[0], "--sizes", str(size), "--reps", "2", *sweep_args[1:]]
-            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=timeout)
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=min(timeout, left))
             if r.returncode != 0:
                 raise RuntimeError(f"rocprofv3 {tag}: rc {r.returncode}: {(r.stderr or r.stdout)[-300:]}")
             vals, durs = {}, []
@@ -235,8 +246,9 @@ def live_counters(kernel_name, shape, avg_launch_ms, key="float", timeout=240):
                 out["profiled_launch_ms"] = round(dur_ns * 1e-6, 3)
         out["counter_passes_s"] = round(time.perf_counter() - t0, 1)
         return out
-    except Exception as exc:   # a counter pass must never take the line down with it
-        sys.stderr.write(f"[bench] live counters for {key} unavailable: {exc!r}\n")
+    except Exception as exc:   # a counter pass must never take the line down with it -- nor hold it up: the first failure ends all passes
+        LIVE_STATE["dead"] = True
+        sys.stderr.write(f"[bench] live counters for {key} unavailable (no further passes in this run): {exc!r}\n")
         return None
     finally:
         shutil.rmtree(workdir, ignore_errors=True)

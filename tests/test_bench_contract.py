@@ -167,3 +167,24 @@ def test_live_counters_are_skipped_quietly_where_they_cannot_run(monkeypatch):
     assert b.live_counters(b.LIVE_KERNEL, (8192,) * 3, 58.0) is None
     assert set(b.LIVE) == {"float", "half", "double", "minplus"}      # the headline + BASELINE C3 / C4 / C5b
     assert b.live_counters("mfma_f16_256x256_pingpong_16x16x32", (16384,) * 3, 47.0, "half") is None   # not the BASELINE size
+
+
+def test_live_counter_passes_share_one_budget_and_stop_at_the_first_failure(monkeypatch):
+    """A hung or unsupported rocprofv3 must not hold the bench line up: every pass is bounded, all passes of a run share one
+    wall-clock budget, and the first failure ends them (the replayed figures stay)."""
+    import shutil
+    import subprocess
+    b = _bench()
+    monkeypatch.delenv("MM_BENCH_NO_PMC", raising=False)
+    monkeypatch.setattr(shutil, "which", lambda name: "/usr/bin/" + name)
+    calls = []
+
+    def fake_run(cmd, **kw):
+        calls.append(kw.get("timeout"))
+        raise subprocess.TimeoutExpired(cmd, kw.get("timeout"))
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    assert b.live_counters(b.LIVE_KERNEL, (16384,) * 3, 58.0) is None
+    assert len(calls) == 1 and 0 < calls[0] <= 75
+    assert b.live_counters("mfma_f16_256x256_pingpong_16x16x32", (32768,) * 3, 47.0, "half") is None
+    assert len(calls) == 1                              # no further passes after the first failure
+    assert b.LIVE_BUDGET_S <= 180
