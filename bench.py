@@ -176,6 +176,8 @@ LIVE = {
     "half": ("mfma_f16_256x256_pingpong_16x16x32", ["f16"], "mfma_f16_", True),
     "double": ("mfma_f64_256x128x16_w8", ["f64"], "mfma_f64_kernel", True),
     "minplus": ("valu_tile", ["minplus"], "valu_tile_", False),
+    "minplus_f64": ("valu_tile", ["minplus_f64"], "valu_tile_", False),
+    "uint8": ("mfma_i8_256x256_pingpong_16x16x64", ["uint8"], "mfma_i8_", True),
 }
 LIVE_KERNEL = LIVE["float"][0]
 
@@ -579,10 +581,10 @@ def main():
         if world == 1 and not args.no_cpu_baseline and headline:
             out["cpu_baseline"] = cpu_baseline()
         if world == 1 and headline and not args.no_extra:
-            # counters measured in this run, after every timed leg: the headline kernel and BASELINE's C3 / C4 / C5b kernels
+            # counters measured in this run, after every timed leg: the headline kernel, BASELINE's C3 / C4 / C5b kernels and the two extras
             targets = [("float", rl, out["config"]["kernel"], (rows, k, m))]
             targets += [(w["key"], w["roofline"], w["kernel"], (WORKLOADS[w["key"]][3],) * 3) for w in out["workloads"]
-                        if w.get("key") in ("half", "double", "minplus") and "roofline" in w]
+                        if w.get("key") in ("half", "double", "minplus", "minplus_f64", "uint8") and "roofline" in w]
             for key, obj, kernel, shape in targets:
                 live = live_counters(kernel, shape, obj["avg_launch_ms"], key)
                 if live:
