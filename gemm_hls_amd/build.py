@@ -31,6 +31,8 @@ COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno
 EXTRA = {
     # the parity anchor must not contract a*b+c into an fma (reference Naive is unfused)
     "mm_ordered.hip": ["-ffp-contract=off"],
+    # the register-tiled kernels under the same k-ordered, unfused contract ("ordered_tile")
+    "mm_valu_tile_fp_exact.hip": ["-ffp-contract=off"],
 }
 
 HOST_CONFIGS = [  # (Data_t, MM_MAP_OP, MM_REDUCE_OP): BASELINE.json configs + an integer semiring
@@ -156,6 +158,9 @@ def build(verbose=True):
     # MM_TRANSPOSED_A builds (CMakeLists.txt:30,100-103): A generated / handed over / verified as K x N
     exe("RunHardware_transposedA_float.exe", "RunHardware.cpp", defs("float", "Multiply", "Add", transposed=True))
     exe("RunHardware_transposedA_int.exe", "RunHardware.cpp", defs("int", "Multiply", "Add", transposed=True))
+    # a half build that keeps the reference's half arithmetic under "hw" (binary16 accumulating in binary16): timed and
+    # verified -- exactly -- on the same kernel
+    exe("RunHardware_half_reference_contract.exe", "RunHardware.cpp", defs("half", mp, rd) + ["-DMM_HALF_CONTRACT_REFERENCE"])
     exe("RunHardware_power.exe", "RunHardware.cpp", defs(dt, mp, rd, power=True))
     # the reference's tile knob (CMakeLists.txt:18-20): a build pinned to the 256 x 256 resident tile
     pin = ["-DMM_MEMORY_TILE_SIZE_N=256", "-DMM_MEMORY_TILE_SIZE_M=256"]
@@ -166,6 +171,7 @@ def build(verbose=True):
     shim(f"libmmkernel_static_float_{tag}.so", defs(dt, mp, rd, static))
     shim("libmmkernel_transposedA.so", defs(dt, mp, rd, transposed=True))
     shim("libmmkernel_half.so", defs("half", mp, rd))
+    shim("libmmkernel_double.so", defs("double", mp, rd))
     # the same library over the k-ordered kernel (MM_PATH_ORDERED): the bit-true "simulation" build.  The reference's own
     # test/TestSimulation.cpp compares half results EXACTLY with its binary16-accumulating Naive (its `half` is not
     # std::is_floating_point, test/TestSimulation.cpp:80-85) -- tests/ref_hosts links it against this one

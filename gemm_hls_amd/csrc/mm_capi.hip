@@ -92,14 +92,19 @@ std::once_flag g_tuning_once;
 std::atomic<int> g_tuning[mm::TUNE_COUNT];
 const char *const kTuneName[mm::TUNE_COUNT] = {"f32_variant", "f64_variant", "f16_variant", "i8_variant", "band_rows",
                                                "valu_variant", "split_variant", "f32_splitk", "ablations", "debug_poison", "kxn_prepass_min_m",
-                                               "md_virtual_devices"};
+                                               "md_virtual_devices", "ordered_variant", "half_contract"};
 const char *const kTuneEnv[mm::TUNE_COUNT] = {"MM_F32_VARIANT", "MM_F64_VARIANT", "MM_F16_VARIANT", "MM_I8_VARIANT",
                                               "MM_BAND_ROWS", "MM_VALU_VARIANT", "MM_SPLIT_VARIANT", "MM_F32_SPLITK", "MM_ABLATIONS", "MM_DEBUG_POISON", "MM_KXN_PREPASS_MIN_M",
-                                              "MM_MD_VIRTUAL_DEVICES"};
+                                              "MM_MD_VIRTUAL_DEVICES", "MM_ORDERED_VARIANT", "MM_HALF_CONTRACT"};
 void tuning_init() {
   for (int i = 0; i < mm::TUNE_COUNT; ++i) {
     const char *e = getenv(kTuneEnv[i]);
-    g_tuning[i].store((e && *e) ? atoi(e) : -1, std::memory_order_relaxed);
+    int v = (e && *e) ? atoi(e) : -1;
+    if (i == mm::TUNE_HALF_CONTRACT && e && *e) {   // the one knob with words for values: MM_HALF_CONTRACT=reference | wide
+      if (strcmp(e, "reference") == 0) v = 1;
+      else if (strcmp(e, "wide") == 0) v = 0;
+    }
+    g_tuning[i].store(v, std::memory_order_relaxed);
   }
 }
 
@@ -125,7 +130,7 @@ bool valid_cfg(const mm_config_t *cfg) {
 int f32_variant() { return mm::tuning(mm::TUNE_F32_VARIANT); }
 int f32_variant_for(const mm::Problem &p) { return mm::mfma_f32_resolve(p, f32_variant()); }  // what the launcher runs; -1: none
 
-enum Family { FAM_ORDERED, FAM_VALU_TILE, FAM_MFMA_F32, FAM_MFMA_F64, FAM_MFMA_F16, FAM_MFMA_I8, FAM_HALF_WIDE,
+enum Family { FAM_ORDERED, FAM_ORDERED_TILE, FAM_VALU_TILE, FAM_MFMA_F32, FAM_MFMA_F64, FAM_MFMA_F16, FAM_MFMA_I8, FAM_HALF_WIDE,
               FAM_F32_SPLIT, FAM_NONE };
 
 // The family is a property of the JOB: a row slab of a bigger job (Problem::n_total) runs the family the whole job would
@@ -135,8 +140,14 @@ enum Family { FAM_ORDERED, FAM_VALU_TILE, FAM_MFMA_F32, FAM_MFMA_F64, FAM_MFMA_F
 Family choose(const mm_config_t &cfg, const mm::Problem &slab) {
   mm::Problem p = slab;
   if (slab.n_total) { p.n = slab.n_total; p.n_total = 0; }
-  if (cfg.path == MM_PATH_ORDERED) return FAM_ORDERED;
   const bool mul_add = cfg.map_op == MM_OP_MULTIPLY && cfg.reduce_op == MM_OP_ADD;
+  // The k-ordered contract (Naive's: include/Utility.h:18-42) has two kernels with the same bits: the register-tiled one
+  // wherever it serves, the fully predicated 64 x 64 one for everything else (and always under ordered_variant = 0).
+  // half (Multiply, Add) under AUTO joins it when the process asked for the REFERENCE's half arithmetic (half_contract = 1:
+  // binary16 accumulating in binary16, kernel/Compute.cpp:129-133 -- what its hosts compare with exactly).
+  const bool reference_half = cfg.path == MM_PATH_AUTO && mul_add && cfg.dtype == MM_DTYPE_F16 && mm::tuning(mm::TUNE_HALF_CONTRACT) == 1;
+  if (cfg.path == MM_PATH_ORDERED || reference_half)
+    return mm::tuning(mm::TUNE_ORDERED_VARIANT) != 0 && mm::valu_tile_serves(cfg, p) ? FAM_ORDERED_TILE : FAM_ORDERED;
   if (cfg.path == MM_PATH_SPLIT)  // an explicit request is never re-routed: fp32 (x,+) or nothing
     return mul_add && cfg.dtype == MM_DTYPE_F32 && mm::mfma_f32_split_serves(p) ? FAM_F32_SPLIT : FAM_NONE;
   if (mul_add && cfg.dtype == MM_DTYPE_F32 && mm::mfma_f32_serves(p)) return FAM_MFMA_F32;
@@ -159,10 +170,11 @@ bool aligned16(const mm::Problem &p) {
 
 int dispatch(hipStream_t s, const mm_config_t &cfg, const mm::Problem &p) {
   if (p.n == 0 || p.m == 0) return MM_OK;  // nothing to write
-  const Family fam = choose(cfg, p);
+  Family fam = choose(cfg, p);
   if (fam == FAM_NONE)
     return fail(MM_ERR_UNSUPPORTED, "MM_PATH_SPLIT serves float (Multiply, Add) only (got dtype %d, map %d, reduce %d)",
                 (int)cfg.dtype, (int)cfg.map_op, (int)cfg.reduce_op);
+  if (fam == FAM_ORDERED_TILE && !aligned16(p)) fam = FAM_ORDERED;   // the k-ordered contract takes any element-aligned pointer
   if (fam != FAM_ORDERED && fam != FAM_HALF_WIDE && fam != FAM_F32_SPLIT && !aligned16(p))
     return fail(MM_ERR_BAD_ARGUMENT, "a, b and c must be 16-byte aligned for the fast path (got %p, %p, %p); "
                 "use an aligned allocation or MM_PATH_ORDERED", p.a, p.b, p.c);
@@ -180,6 +192,10 @@ int dispatch(hipStream_t s, const mm_config_t &cfg, const mm::Problem &p) {
     case FAM_VALU_TILE:
       e = mm::launch_valu_tile(s, cfg, p);
       if (e == mm::kErrNotSupported) e = mm::launch_ordered(s, cfg, p);  // still the GPU
+      break;
+    case FAM_ORDERED_TILE:
+      e = mm::launch_valu_tile_exact(s, cfg, p);
+      if (e == mm::kErrNotSupported) e = mm::launch_ordered(s, cfg, p);  // the same bits
       break;
     default: e = mm::launch_ordered(s, cfg, p); break;
   }
@@ -707,6 +723,7 @@ const char *mm_kernel_name(const mm_config_t *cfg, unsigned n, unsigned k, unsig
     case FAM_F32_SPLIT: return "mfma_f32_split_bf16x3";
     case FAM_NONE: return "unsupported";
     case FAM_VALU_TILE: return "valu_tile";
+    case FAM_ORDERED_TILE: return "ordered_tile";   // k ascending, one accumulator, unfused: Naive's bits on 128 x 128 register tiles
     default: return "ordered";
   }
 }
@@ -775,6 +792,16 @@ static void kernel_info_for(const mm_config_t *cfg, const mm::Problem &p, mm_ker
       r.ops_per_clk_per_cu = 4096.0 / 6.0;  // six bf16 MFMAs per fp32 multiply-add block
       r.measured_issue_efficiency = 0.90;
       break;
+    case FAM_ORDERED_TILE: {
+      r.tile_n = 128; r.tile_m = 128; r.tile_k = (unsigned)(64 / mm_dtype_size(cfg->dtype)); r.wavefronts = mm_dtype_size(cfg->dtype) == 8 ? 8 : 4;
+      r.inst_n = 1; r.inst_m = 64; r.inst_k = 1;
+      // one instruction per operation (multiply and add are NOT fused here).  4-byte types: 2-cycle issue, 128 operations per
+      // clock per CU; half: v_pk_mul_f16 / v_pk_add_f16 take two elements per lane but issue every 4 cycles (measured 4.30:
+      // profiles/r06a_probe_valu_issue_rates_unfused_pairs.txt) -- the same 128; 8-byte types: 4-cycle issue, 64
+      r.ops_per_clk_per_cu = mm_dtype_size(cfg->dtype) == 8 ? 64.0 : 128.0;
+      r.measured_issue_efficiency = cfg->dtype == MM_DTYPE_F16 ? 0.94 : 0.74;   // half 74.4 / float 58.4 / double 28.9 TOp/s at 8192^3 (r06a)
+      break;
+    }
     case FAM_VALU_TILE: {
       r.tile_n = 128; r.tile_m = 128; r.tile_k = 16; r.wavefronts = 4;
       r.inst_n = 1; r.inst_m = 64; r.inst_k = 1;

@@ -85,6 +85,10 @@ int launch_ordered(hipStream_t s, const mm_config_t &cfg, const Problem &p);
 int launch_half_wide(hipStream_t s, const Problem &p);  // half (x,+), f32 accumulate, any shape
 int launch_valu_tile(hipStream_t s, const mm_config_t &cfg, const Problem &p);
 bool valu_tile_serves(const mm_config_t &cfg, const Problem &p);
+// The same register-tiled kernels under the k-ORDERED contract ("ordered_tile"): floating-point types from the unit compiled
+// with contraction off and Op<> to the letter (mm_valu_tile_fp_exact.hip); the integer types' kernels are bit-identical to
+// Naive as they are.  Serves whenever valu_tile_serves() and the operands are 16-byte aligned.
+int launch_valu_tile_exact(hipStream_t s, const mm_config_t &cfg, const Problem &p);
 int launch_mfma_f32(hipStream_t s, const Problem &p, int variant);
 int launch_mfma_f64(hipStream_t s, const Problem &p);
 int launch_mfma_f16(hipStream_t s, const Problem &p);
@@ -154,6 +158,11 @@ enum Tunable {
   TUNE_KXN_PREPASS_MIN_M,  // MM_KXN_PREPASS_MIN_M  half / int8 with a K x N A: M from which the transposition pre-pass is taken (-1: 6144)
   TUNE_MD_VIRTUAL_DEVICES, // MM_MD_VIRTUAL_DEVICES  G > 0: mm_gemm_multi_device accepts device_count <= G and deals its logical devices
                            //                 out over the physical ones round-robin (tests: every g > 0 branch on a 1-GPU box)
+  TUNE_ORDERED_VARIANT,    // MM_ORDERED_VARIANT  0 = MM_PATH_ORDERED always runs the 64 x 64 kernel of mm_ordered.hip (the cross-check);
+                           //                 else (default) the register-tiled k-ordered kernel wherever it serves -- same bits
+  TUNE_HALF_CONTRACT,      // MM_HALF_CONTRACT  1 / "reference": half (Multiply, Add) under MM_PATH_AUTO keeps the REFERENCE's arithmetic
+                           //                 (binary16 products and binary16 accumulation, k ascending: kernel/Compute.cpp:129-133) on the
+                           //                 k-ordered tile kernel instead of the matrix cores' f32 accumulation; 0 / "wide" / unset: f32
   TUNE_COUNT
 };
 int tuning(Tunable t);  // mm_capi.hip

@@ -62,6 +62,11 @@ struct DeviceBuffer {
 
 int main(int argc, char **argv) {
   mmhost::ApplyBuildTimeTile();   // -DMM_MEMORY_TILE_SIZE_N/M: pin the resident tile if the library has that geometry
+#ifdef MM_HALF_CONTRACT_REFERENCE
+  // a half build that keeps the reference's arithmetic under "hw" too (binary16 accumulating in binary16,
+  // kernel/Compute.cpp:129-133); the same as MM_HALF_CONTRACT=reference in the environment
+  mm_tuning_set("half_contract", 1);
+#endif
   bool emulation = false;
   bool verify = true;
 #ifdef MM_DYNAMIC_SIZES
@@ -247,7 +252,13 @@ int main(int argc, char **argv) {
     const auto t0 = std::chrono::steady_clock::now();
     // hw_emu runs the k-ordered kernel, which follows the reference's Naive to the bit -- for half
     // that means accumulating in binary16, so it is checked against exactly that, exactly
-    const bool half_emulation = emulation && mmhost::IsHalf<Data_t>::value;
+    // -- and so does "hw" when the process asked for the reference's half contract (MM_HALF_CONTRACT=reference /
+    // -DMM_HALF_CONTRACT_REFERENCE): timed AND verified on the same kernel, with the reference's exact comparison
+    int half_contract = -1;
+    (void)mm_tuning_get("half_contract", &half_contract);
+    const bool reference_half = std::is_same<OperatorMap, mmhost::op::Multiply<Data_t>>::value &&
+                                std::is_same<OperatorReduce, mmhost::op::Add<Data_t>>::value && half_contract == 1;
+    const bool half_emulation = (emulation || reference_half) && mmhost::IsHalf<Data_t>::value;
     mmhost::ReferenceImplementation<Data_t, OperatorMap, OperatorReduce>(a.data(), b.data(), cRef.data(), size_n, size_k,
                                                                          size_m, kTransposedA, half_emulation);
     const double tref = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

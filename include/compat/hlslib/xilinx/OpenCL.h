@@ -26,11 +26,17 @@
  *     MakeKernel(name, a, b, c[, N, K, M])   binds mm_gemm_launch with the configuration of THIS build: Data_t,
  *                        OperatorMap, OperatorReduce from the build's generated Config.h (include/Config.h.in:15,34-35),
  *                        MM_TRANSPOSED_A -> a K x N A, and kSizeN/K/M when the build has static sizes (3-argument form)
- *     ExecuteTask()      one untimed launch the first time in a process (code-object upload, clock ramp; C is pure
- *                        output, kernel/Top.cpp never reads it, so running twice changes nothing), then the timed
- *                        launch; returns {seconds, seconds} measured with HIP events on the launch stream
+ *     ExecuteTask()      one untimed launch the first time a Kernel object runs (code-object upload, LDS opt-in, clock ramp
+ *                        -- per kernel, shape and device; C is pure output, kernel/Top.cpp never reads it, so running twice
+ *                        changes nothing), then the timed launch; returns {seconds, seconds} measured with HIP events on the
+ *                        launch stream
  *     XCL_EMULATION_MODE=hw_emu (set by RunHardware.cpp:76 for "hw_emu")   the k-ordered kernel (MM_PATH_ORDERED),
  *                        bit-identical to the reference's Naive; anything else: the fast path (MM_PATH_AUTO)
+ *     -DMM_HALF_CONTRACT_REFERENCE (or MM_HALF_CONTRACT=reference in the environment)   a half build keeps the REFERENCE's
+ *                        arithmetic under "hw" as well: binary16 products accumulated in binary16, k ascending
+ *                        (kernel/Compute.cpp:129-133), on the register-tiled k-ordered kernel -- the result its hosts compare
+ *                        with exactly (test/TestSimulation.cpp:80-85, host/RunHardware.cpp:214-218).  Default: the matrix
+ *                        cores, f32 accumulation, one rounding (more accurate, not equal)
  *
  * Errors surface as hlslib::ocl::RuntimeError / ConfigurationError, both std::runtime_error, so the reference's one catch
  * block (RunHardware.cpp:192-196) prints them and returns 1.  No CPU fallback: without an MI355X the Context throws.
@@ -134,6 +140,13 @@ inline mm_config_t BuildConfig() {
   return cfg;
 }
 
+/* seeds of the device-side fills: ONE counter for every Buffer instantiation, so that A and B never get the same stream
+ * (a per-template static would start both MemoryPackK_t and MemoryPackM_t buffers at the same seed) */
+inline unsigned long long NextFillSeed() {
+  static unsigned long long seed = 0x5eed;
+  return ++seed;
+}
+
 }  // namespace detail
 
 template <typename T, Access access>
@@ -145,8 +158,7 @@ class Buffer {
   Buffer(int device, std::size_t elements) : device_(device), elements_(elements) {
     detail::Check(mm_alloc(device_, bytes(), &pointer_), "MakeBuffer (mm_alloc)");
     if (access == Access::read && elements_ > 0) {
-      static unsigned long long seed = 0x5eed;
-      const int rc = mm_fill_device(device_, detail::DTypeOf<Element_t>::value, pointer_, bytes() / sizeof(Element_t), ++seed);
+      const int rc = mm_fill_device(device_, detail::DTypeOf<Element_t>::value, pointer_, bytes() / sizeof(Element_t), detail::NextFillSeed());
       if (rc != MM_OK) {
         const std::string message = std::string("MakeBuffer (mm_fill_device): ") + mm_last_error();
         (void)mm_free(device_, pointer_);
@@ -203,10 +215,9 @@ class Kernel {
    * divides the operation count by .first */
   std::pair<double, double> ExecuteTask() {
     const mm_config_t cfg = detail::BuildConfig();
-    static bool warmed_up = false;
-    if (!warmed_up) {
+    if (!warmed_up_) {
       detail::Check(mm_gemm_launch(device_, &cfg, a_, b_, c_, n_, k_, m_, nullptr), "ExecuteTask (first launch)");
-      warmed_up = true;
+      warmed_up_ = true;
     }
     double seconds = 0.0;
     detail::Check(mm_gemm_launch(device_, &cfg, a_, b_, c_, n_, k_, m_, &seconds), "ExecuteTask (mm_gemm_launch)");
@@ -224,6 +235,7 @@ class Kernel {
   const void *a_, *b_;
   void *c_;
   unsigned n_, k_, m_;
+  bool warmed_up_ = false;   /* per Kernel object: another shape / configuration / device pays its own first launch untimed */
 };
 
 class Program {
@@ -271,6 +283,9 @@ class Context {
     if (rc != MM_OK) throw ConfigurationError(std::string("no usable device: ") + mm_last_error());
     if (device_ < 0 || device_ >= count)
       throw ConfigurationError("device index " + std::to_string(device_) + " out of range: " + std::to_string(count) + " MI355X visible");
+#ifdef MM_HALF_CONTRACT_REFERENCE
+    detail::Check(mm_tuning_set("half_contract", 1), "half_contract = reference");
+#endif
   }
   /* hlslib's (vendor, device name) form: the names are Xilinx's and mean nothing here */
   Context(std::string const &, std::string const &) : Context(0) {}

@@ -27,7 +27,11 @@ typedef enum {
   MM_DTYPE_F16 = 2, /* half (IEEE binary16).  (Multiply, Add) under MM_PATH_AUTO: exact products,
                        f32 accumulation, ONE rounding on store, for EVERY shape (matrix cores when
                        K % 16 == 0 and M % 8 == 0, a plain wide-accumulate kernel otherwise);
-                       MM_PATH_ORDERED accumulates in binary16 exactly like the reference */
+                       MM_PATH_ORDERED accumulates in binary16 exactly like the reference
+                       (kernel/Compute.cpp:129-133), and so does MM_PATH_AUTO once the process asked for
+                       the REFERENCE's half contract: mm_tuning_set("half_contract", 1) /
+                       MM_HALF_CONTRACT=reference -- the result the reference's hosts compare with
+                       EXACTLY (test/TestSimulation.cpp:80-85, host/RunHardware.cpp:214-218) */
   MM_DTYPE_I8 = 3,  /* int8_t         */
   MM_DTYPE_U8 = 4,  /* uint8_t        */
   MM_DTYPE_I16 = 5, /* short          */
@@ -62,7 +66,11 @@ typedef enum {
  *                    Naive does -- acc = identity; for k ascending: acc = Reduce(acc, Map(a,b)),
  *                    multiply and add NOT fused -- bit-identical to include/Utility.h:18-42
  *                    for every dtype; == RunHardware "hw_emu" (a slower, independently written
- *                    execution of the same contract on the same device).
+ *                    execution of the same contract on the same device).  Two kernels with the same
+ *                    bits serve it: "ordered_tile", 128 x 128 register tiles (K % 4 == 0, M % 4 == 0,
+ *                    16-byte aligned operands; half 74, float 58, double 29 TOp/s at 8192^3), and
+ *                    "ordered", fully predicated 64 x 64 tiles, for everything else ("ordered_variant"
+ *                    = 0 forces it: the cross-check).
  *   MM_PATH_SPLIT    float (Multiply, Add) only, opt-in: fp32 operands split into three bf16
  *                    planes (all 24 significand bits), six bf16 matrix-core products per
  *                    element pair accumulated in fp32 -- each product good to ~2^-25, i.e. at
@@ -220,7 +228,10 @@ typedef struct {
 int mm_kernel_info(const mm_config_t *cfg, unsigned size_n, unsigned size_k, unsigned size_m,
                    mm_kernel_info_t *info);
 /* Tuning knobs for sweeps ("f32_variant", "f64_variant", "f16_variant", "i8_variant", "valu_variant", "split_variant",
- * "band_rows", "f32_splitk"; -1 = the library's own choice).  Kernel ids of this library: f32_variant 33 / 8 / 35 / 64 (the
+ * "band_rows", "f32_splitk", "ordered_variant"; -1 = the library's own choice) and ONE contract knob, "half_contract"
+ * (MM_HALF_CONTRACT = reference | wide; 1 = reference: half (Multiply, Add) under MM_PATH_AUTO is evaluated like the reference's
+ * kernel -- binary16 products, binary16 accumulation, k ascending -- on the k-ordered tile kernel; unset / 0: f32 accumulation on
+ * the matrix cores).  Kernel ids of this library: f32_variant 33 / 8 / 35 / 64 (the
  * geometries of the shape-adaptive pick) and 0 / 3 (cross-checks); f16_variant 200 / 100 / 11 / 0 / 4 / 5; i8_variant 200 /
  * 100 / 10 / 5 / 0; f64_variant 0-4 (4: the 64 x 64 geometry for small problems); f32_splitk 1 whole tiles, 2-8 K chunks,
  * 0 stream-K as MM_PATH_AUTO runs it: teams of workgroups, every part of a tile that a range boundary cuts goes to a scratch

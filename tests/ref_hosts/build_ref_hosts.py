@@ -29,6 +29,12 @@ OUT = os.path.join(ROOT, "bin", "ref_hosts")
 CXX = os.environ.get("MM_HOST_CXX", "/opt/rocm/lib/llvm/bin/clang++")   # half needs _Float16 on the host: clang, not g++ 11
 WIDTH = {"float": 4, "int": 4, "unsigned": 4, "double": 8, "long": 8, "half": 2, "short": 2, "uint8_t": 1, "char": 1}
 
+# The BLAS the reference's oracle is linked against in the *_blas configurations (its CMake: find_package(BLAS), -DMM_HAS_BLAS,
+# CMakeLists.txt:75-85,151,205).  This image ships MKL's single dynamic library without headers: tests/ref_hosts/blas/cblas.h
+# declares the two CBLAS entry points include/Utility.h:76-103 calls.
+SYSTEM_LIB_DIR = "/usr/lib/x86_64-linux-gnu"
+BLAS_LIBRARY = os.environ.get("MM_BLAS_LIBRARY", "/opt/conda/lib/libmkl_rt.so")
+
 # name -> (MM_DATA_TYPE, MM_MAP_OP, MM_REDUCE_OP, transposed A, static sizes or None, kernel library for TestSimulation or None)
 STATIC = (528, 512, 560)
 CONFIGS = {
@@ -36,11 +42,19 @@ CONFIGS = {
     # half: the reference's verification is EXACT for half (its `half` class is not std::is_floating_point), against a Naive
     # that accumulates in binary16 -- so its TestSimulation gets the kernel library over the k-ordered kernel
     "half": ("half", "Multiply", "Add", False, None, "libmmkernel_half_ordered.so"),
+    # the same half build with -DMM_HALF_CONTRACT_REFERENCE (include/compat): "hw" keeps the reference's half arithmetic on the
+    # k-ordered tile kernel, so the reference's own exact comparison holds for the timed kernel too
+    "half_reference_contract": ("half", "Multiply", "Add", False, None, None),
     "float_transposedA": ("float", "Multiply", "Add", True, None, "libmmkernel_transposedA.so"),
     "float_static_%dx%dx%d" % STATIC: ("float", "Multiply", "Add", False, STATIC, "libmmkernel_static_float_%dx%dx%d.so" % STATIC),
     "float_Add_Min": ("float", "Add", "Min", False, None, None),
     "int": ("int", "Multiply", "Add", False, None, None),
     "double": ("double", "Multiply", "Add", False, None, None),
+    # the reference's hosts WITH its BLAS oracle (-DMM_HAS_BLAS): "Running BLAS..." instead of the Naive fall-back, so they can
+    # verify BASELINE C2 / C4 (16384^3) themselves.  (No transposed-A BLAS build: the reference passes lda = size_k with
+    # CblasTrans, include/Utility.h:86-87,99-100 -- right only for N == K; a reference defect)
+    "float_blas": ("float", "Multiply", "Add", False, None, "libmmkernel.so"),
+    "double_blas": ("double", "Multiply", "Add", False, None, "libmmkernel_double.so"),
 }
 
 
@@ -88,8 +102,18 @@ def build(verbose=True):
         flags += [] if sizes else ["-DMM_DYNAMIC_SIZES"]
         flags += ["-DMM_TRANSPOSED_A"] if transposed else []
         flags += ["-DMM_HALF_PRECISION"] if dtype == "half" else []
+        flags += ["-DMM_HALF_CONTRACT_REFERENCE"] if name == "half_reference_contract" else []
         rpath = "-Wl,-rpath,$ORIGIN/../../../gemm_hls_amd:$ORIGIN/../.."
         device = ["-L" + lib_dir, "-lmm_gemm_amd", rpath]
+        if name.endswith("_blas"):
+            if not os.path.exists(BLAS_LIBRARY):
+                if verbose:
+                    print(f"build_ref_hosts: {BLAS_LIBRARY} not found - skipping {name} (set MM_BLAS_LIBRARY)")
+                continue
+            flags += ["-DMM_HAS_BLAS", "-I" + os.path.join(ROOT, "tests", "ref_hosts", "blas")]
+            # the BLAS's directory goes LAST on the run path, behind the system's library directory: /opt/conda/lib also holds an
+            # older libstdc++ than the one libmm_gemm_amd.so was linked against, which must not be the one that gets loaded
+            device += [BLAS_LIBRARY, "-Wl,--disable-new-dtags", "-Wl,-rpath," + SYSTEM_LIB_DIR + ":" + os.path.dirname(BLAS_LIBRARY)]
         run([CXX] + flags + [os.path.join(REF, "host", "RunHardware.cpp"), "-o", os.path.join(out, "RunHardware.exe")] + device)
         built.append(os.path.join(out, "RunHardware.exe"))
         if kernel_lib:   # the reference's `mmkernel` role: first in link order, so its MatrixMultiplicationKernel is the one bound

@@ -48,7 +48,18 @@ def test_enum_values_agree_header_binding_oracle():
 
 def test_kernel_name_dispatch_table():
     assert g.kernel_name(g.make_config("float"), 16384, 16384, 16384).startswith("mfma_f32")
-    assert g.kernel_name(g.make_config("float", path=g.PATH_ORDERED), 64, 64, 64) == "ordered"
+    # the k-ordered contract: the register-tiled kernel where it serves (K % 4 == 0, M % 4 == 0, reductions Add / Min / Max and a
+    # map other than And), the fully predicated 64 x 64 kernel for the rest -- and always under ordered_variant = 0
+    assert g.kernel_name(g.make_config("float", path=g.PATH_ORDERED), 64, 64, 64) == "ordered_tile"
+    assert g.kernel_name(g.make_config("float", path=g.PATH_ORDERED), 64, 62, 64) == "ordered"
+    assert g.kernel_name(g.make_config("int", "And", "Add", path=g.PATH_ORDERED), 64, 64, 64) == "ordered"
+    assert g.kernel_name(g.make_config("float", "Multiply", "Multiply", path=g.PATH_ORDERED), 64, 64, 64) == "ordered"
+    assert g.kernel_name(g.make_config("float", path=g.PATH_ORDERED, transposed_a=True), 62, 64, 64) == "ordered"   # K x N A: N % 4
+    try:
+        g.set_tuning("ordered_variant", 0)
+        assert g.kernel_name(g.make_config("float", path=g.PATH_ORDERED), 64, 64, 64) == "ordered"
+    finally:
+        g.set_tuning("ordered_variant", -1)
     assert not g.kernel_name(g.make_config("float", "Add", "Min"), 64, 64, 64).startswith("mfma")
     assert not g.kernel_name(g.make_config("float"), 64, 62, 64).startswith("mfma")  # K % 8 != 0
     assert g.kernel_name(g.make_config("float", "Add", "Min"), 64, 64, 64) == "valu_tile"
@@ -95,8 +106,43 @@ def test_half_auto_path_never_falls_back_to_half_accumulation():
     assert g.kernel_name(g.make_config("half"), 512, 4096, 512).startswith("mfma_f16_")
     assert g.kernel_name(g.make_config("half"), 512, 4104, 512) == "ordered_wide_f16"
     assert g.kernel_name(g.make_config("half"), 512, 4096, 516) == "ordered_wide_f16"
-    assert g.kernel_name(g.make_config("half", path=g.PATH_ORDERED), 512, 4104, 512) == "ordered"
+    assert g.kernel_name(g.make_config("half", path=g.PATH_ORDERED), 512, 4104, 512) == "ordered_tile"
+    assert g.kernel_name(g.make_config("half", path=g.PATH_ORDERED), 512, 4102, 512) == "ordered"
     assert g.kernel_name(g.make_config("half", "Add", "Min"), 512, 4104, 512) == "valu_tile"
+
+
+def test_half_contract_knob_routes_only_half_multiply_add_of_the_auto_path():
+    """half_contract = 1 (MM_HALF_CONTRACT=reference): half (Multiply, Add) under MM_PATH_AUTO takes the k-ordered kernels
+    (the reference's binary16-accumulating arithmetic); nothing else moves, and an explicit MM_PATH_SPLIT stays refused."""
+    assert g.get_tuning("half_contract") == -1
+    try:
+        g.set_tuning("half_contract", 1)
+        assert g.kernel_name(g.make_config("half"), 32768, 32768, 32768) == "ordered_tile"
+        assert g.kernel_name(g.make_config("half"), 513, 542, 544) == "ordered"
+        assert g.kernel_name(g.make_config("half", transposed_a=True), 4096, 4096, 4096) == "ordered_tile"
+        assert g.kernel_name(g.make_config("half", "Add", "Min"), 512, 512, 512) == "valu_tile"
+        assert g.kernel_name(g.make_config("float"), 16384, 16384, 16384).startswith("mfma_f32")
+        assert g.kernel_name(g.make_config("uint8_t"), 4096, 512, 4096).startswith("mfma_i8")
+        assert g.kernel_name(g.make_config("half", path=g.PATH_SPLIT), 512, 512, 512) == "unsupported"
+        info = g.kernel_info(g.make_config("half"), 32768, 32768, 32768)
+        assert (info.tile_n, info.tile_m, info.tile_k, info.inst_m) == (128, 128, 32, 64) and info.ops_per_clk_per_cu == 128.0
+        g.set_tuning("half_contract", 0)
+        assert g.kernel_name(g.make_config("half"), 32768, 32768, 32768).startswith("mfma_f16")
+    finally:
+        g.set_tuning("half_contract", -1)
+
+
+@pytest.mark.parametrize("value,want", [("reference", 1), ("wide", 0), ("1", 1), ("0", 0)])
+def test_half_contract_knob_is_read_from_the_environment_once(value, want):
+    """MM_HALF_CONTRACT is the one knob with words for values; like the others it is read when the library initialises."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); import gemm_hls_amd as g; "
+            "print(g.get_tuning('half_contract'), g.kernel_name(g.make_config('half'), 4096, 4096, 4096))" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, MM_HALF_CONTRACT=value), capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    got, name = r.stdout.split()
+    assert int(got) == want and (name == "ordered_tile") == (want == 1)
 
 
 def test_tuning_knobs_are_library_state_not_environment(monkeypatch):

@@ -28,10 +28,12 @@ SHAPES = [(513, 528, 528), (1, 16, 16), (37, 32, 48), (300, 64, 272), (129, 80, 
 @pytest.fixture(autouse=True)
 def _default_tuning():
     """Every test starts and ends on the library's own geometry choice (knobs are process-wide)."""
-    for knob in ("f32_variant", "f64_variant", "f16_variant", "i8_variant", "band_rows", "valu_variant", "f32_splitk"):
+    knobs = ("f32_variant", "f64_variant", "f16_variant", "i8_variant", "band_rows", "valu_variant", "f32_splitk", "ordered_variant",
+             "half_contract")
+    for knob in knobs:
         g.set_tuning(knob, -1)
     yield
-    for knob in ("f32_variant", "f64_variant", "f16_variant", "i8_variant", "band_rows", "valu_variant", "f32_splitk"):
+    for knob in knobs:
         g.set_tuning(knob, -1)
 
 
@@ -663,14 +665,89 @@ ORDERED_CASES = [
 
 
 @pytest.mark.parametrize("dtype,mp,rd", ORDERED_CASES, ids=lambda x: str(x))
-@pytest.mark.parametrize("shape", [(65, 48, 80), (129, 33, 70)], ids=lambda s: "x".join(map(str, s)))
-def test_ordered_path_is_bit_identical_to_naive(dtype, mp, rd, shape):
-    """MM_PATH_ORDERED (RunHardware hw_emu) == include/Utility.h:18-42, bit for bit, any shape."""
+@pytest.mark.parametrize("shape", [(65, 48, 80), (129, 33, 70), (257, 264, 272)], ids=lambda s: "x".join(map(str, s)))
+@pytest.mark.parametrize("kernel", ["tile_where_it_serves", "anchor_64x64"])
+def test_ordered_path_is_bit_identical_to_naive(dtype, mp, rd, shape, kernel):
+    """MM_PATH_ORDERED (RunHardware hw_emu) == include/Utility.h:18-42, bit for bit, any shape -- from BOTH kernels that serve
+    the contract: the register-tiled one (K % 4 == 0 and M % 4 == 0: the first and third shape) and the 64 x 64 anchor."""
     n, k, m = shape
+    g.set_tuning("ordered_variant", 0 if kernel == "anchor_64x64" else -1)
+    tiled = kernel != "anchor_64x64" and k % 4 == 0 and m % 4 == 0 and mp != "And" and rd in ("Add", "Min", "Max")
+    assert g.kernel_name(g.make_config(dtype, mp, rd, g.PATH_ORDERED), n, k, m) == ("ordered_tile" if tiled else "ordered")
     a, b = _oracle.fill(dtype, n, k, m)
     c, _ = g.matmul_capi(a, b, dtype, mp, rd, path=g.PATH_ORDERED)
     want = _oracle.naive(dtype, mp, rd, a, b)
     assert np.array_equal(c.view(np.uint8), want.view(np.uint8))
+
+
+def _same_bits_up_to_nan_payload(x, y):
+    """Bit equality with all NaNs taken as one value: which of two NaN operands an addition hands on is not specified by
+    IEEE 754 and follows the instruction's operand order, which two compilations of the same expression need not share."""
+    if x.dtype.kind != "f":
+        return np.array_equal(x, y)
+    u = {2: np.uint16, 4: np.uint32, 8: np.uint64}[x.dtype.itemsize]
+    nx, ny = np.isnan(x), np.isnan(y)
+    return np.array_equal(nx, ny) and np.array_equal(x.view(u)[~nx], y.view(u)[~ny])
+
+
+@pytest.mark.parametrize("dtype", ["half", "float", "double"])
+@pytest.mark.parametrize("mp,rd", [("Multiply", "Add"), ("Add", "Min"), ("Add", "Max"), ("Min", "Max"), ("Max", "Min"), ("Min", "Add"),
+                                   ("Multiply", "Max"), ("Add", "Add")])
+@pytest.mark.parametrize("transposed_a", [False, True], ids=["nxk", "kxn"])
+def test_ordered_tile_equals_the_anchor_kernel_on_specials(dtype, mp, rd, transposed_a):
+    """The two k-ordered kernels on operands with NaN, +-inf, +-0 and mixed signs sprinkled in: std::min / std::max to the letter
+    (a NaN operand, signed-zero ties), IEEE inf arithmetic, overflow of binary16 sums -- the same bits element for element, in
+    the DMA-staged and the synchronous staging of the tile kernel (row-major and K x N A)."""
+    rng = np.random.default_rng(66)
+    n, k, m = 260, 264, 272
+    npdt = {"half": np.float16, "float": np.float32, "double": np.float64}[dtype]
+    a = rng.uniform(-4, 10, size=(k, n) if transposed_a else (n, k)).astype(npdt)
+    b = rng.uniform(-4, 10, size=(k, m)).astype(npdt)
+    for arr in (a, b):
+        flat = arr.reshape(-1)
+        idx = rng.integers(0, flat.size, size=flat.size // 97)
+        flat[idx] = rng.choice(np.array([np.nan, np.inf, -np.inf, 0.0, -0.0], dtype=npdt), size=idx.size)
+    assert g.kernel_name(g.make_config(dtype, mp, rd, g.PATH_ORDERED, transposed_a), n, k, m) == "ordered_tile"
+    c_tile, _ = g.matmul_capi(a, b, dtype, mp, rd, path=g.PATH_ORDERED, transposed_a=transposed_a)
+    g.set_tuning("ordered_variant", 0)
+    c_anchor, _ = g.matmul_capi(a, b, dtype, mp, rd, path=g.PATH_ORDERED, transposed_a=transposed_a)
+    assert _same_bits_up_to_nan_payload(c_tile, c_anchor)
+    # the sprinkling reached the outputs and did not drown them (a Min / Max reduction written as std::min / std::max DROPS a
+    # NaN operand -- `b < a ? b : a` keeps the accumulator -- so only the Add reductions must show NaNs)
+    assert np.isfinite(c_tile).any() and (rd != "Add" or np.isnan(c_tile).any())
+    assert not np.isfinite(c_tile).all()
+
+
+def test_ordered_tile_takes_unaligned_operands_to_the_anchor_kernel():
+    """MM_PATH_ORDERED takes any element-aligned pointer (include/mm_gemm.h): an offset view falls back to the predicated
+    kernel instead of being refused, with the same bits."""
+    import torch
+    n, k, m = 128, 64, 128
+    a, b = _oracle.fill("float", n, k, m)
+    buf = torch.zeros(n * k + 1, dtype=torch.float32, device="cuda")
+    buf[1:] = torch.from_numpy(a.reshape(-1)).cuda()
+    c = g.matmul(buf[1:].view(n, k), torch.from_numpy(b).cuda(), path=g.PATH_ORDERED).cpu().numpy()
+    assert np.array_equal(c, _oracle.naive("float", "Multiply", "Add", a, b))
+
+
+@pytest.mark.parametrize("shape", [(513, 544, 544), (300, 64, 288), (64, 4096, 64), (129, 30, 70)], ids=lambda s: "x".join(map(str, s)))
+def test_half_reference_contract_under_auto_is_the_reference_arithmetic(shape):
+    """half_contract = reference (MM_HALF_CONTRACT=reference): half (Multiply, Add) under MM_PATH_AUTO is the reference kernel's
+    own arithmetic -- binary16 products, binary16 accumulation, k ascending (kernel/Compute.cpp:129-133) -- bit for bit equal
+    to Naive (include/Utility.h:29-37), incl. where the binary16 sum overflows (K = 4096 on [1,10): inf) and on shapes only
+    the predicated kernel takes; other configurations are untouched by the knob."""
+    n, k, m = shape
+    a, b = _oracle.fill("half", n, k, m)
+    want = _oracle.naive("half", "Multiply", "Add", a, b)
+    wide, _ = g.matmul_capi(a, b, "half")
+    g.set_tuning("half_contract", 1)
+    assert g.kernel_name(g.make_config("half"), n, k, m) == ("ordered_tile" if k % 4 == 0 and m % 4 == 0 else "ordered")
+    c, _ = g.matmul_capi(a, b, "half")
+    assert np.array_equal(c.view(np.uint16), want.view(np.uint16))
+    if k >= 64 and k < 4096:
+        assert not np.array_equal(c.view(np.uint16), wide.view(np.uint16))     # the default contract rounds once: other bits
+    assert g.kernel_name(g.make_config("float"), n, 528, 528).startswith("mfma_f32")
+    assert g.kernel_name(g.make_config("half", "Add", "Min"), 512, 512, 512) == "valu_tile"
 
 
 def test_ordered_path_reference_ctest_shape_float():
@@ -767,8 +844,18 @@ def test_against_reference_kernel_golden_outputs(path, dtype, mp, rd, shape, ta)
     n, k, m = shape
     a, b = _oracle.fill(dtype, n, k, m, transposed_a=ta)
     ref = np.load(path)["c"]
+    assert g.kernel_name(g.make_config(dtype, mp, rd, g.PATH_ORDERED, ta), n, k, m) == "ordered_tile"
     c_ord, _ = g.matmul_capi(a, b, dtype, mp, rd, path=g.PATH_ORDERED, transposed_a=ta)
     assert np.array_equal(c_ord, ref)  # same k-ordered unfused chain -> bit-identical, floats too
+    g.set_tuning("ordered_variant", 0)  # ... from the 64 x 64 anchor kernel as well
+    c_anchor, _ = g.matmul_capi(a, b, dtype, mp, rd, path=g.PATH_ORDERED, transposed_a=ta)
+    g.set_tuning("ordered_variant", -1)
+    assert np.array_equal(c_anchor, ref)
+    if dtype == "half":                 # the reference's half contract under AUTO: the golden bits, not a tolerance
+        g.set_tuning("half_contract", 1)
+        c_ref_contract, _ = g.matmul_capi(a, b, dtype, mp, rd, transposed_a=ta)
+        g.set_tuning("half_contract", -1)
+        assert np.array_equal(c_ref_contract.view(np.uint16), ref.view(np.uint16))
     c, _ = g.matmul_capi(a, b, dtype, mp, rd, transposed_a=ta)
     if dtype == "float":
         assert _oracle.compare("float", c, ref, F32_TOL)[0] == 0

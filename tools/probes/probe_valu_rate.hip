@@ -17,6 +17,7 @@
 #include <vector>
 #include <algorithm>
 typedef float f2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 #define ITERS 32768
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 
@@ -30,6 +31,9 @@ __global__ __launch_bounds__(1024) void k(float *out, unsigned long long *cyc, f
   for (int i = 0; i < 16; ++i) a[i] = threadIdx.x + i;
   for (int i = 0; i < 8; ++i) p[i] = f2{(float)threadIdx.x, (float)i};
   const f2 xy = {x, y};
+  h2 hp[16];       // round 6: the unfused multiply-add steps of the k-ordered tile kernel (mm_valu_tile_fp_exact.hip)
+  for (int i = 0; i < 16; ++i) hp[i] = h2{(_Float16)(threadIdx.x & 7), (_Float16)i};
+  const h2 hxy = {(_Float16)x, (_Float16)y};
   __syncthreads();
   const unsigned long long t0 = __builtin_amdgcn_s_memtime();
   for (int it = 0; it < ITERS; ++it) {
@@ -50,6 +54,30 @@ __global__ __launch_bounds__(1024) void k(float *out, unsigned long long *cyc, f
         double s0;
         asm volatile("v_add_f64 %0, %1, %2" : "=v"(s0) : "v"(dx), "v"(da[(i + 1) & 15]));
         asm volatile("v_min_f64 %0, %0, %1" : "+v"(da[i]) : "v"(s0));
+      }
+      if (MODE == 14) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[i]) : "v"(x));
+      if (MODE == 15) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p[i & 7]) : "v"(xy));
+      if (MODE == 16) asm volatile("v_pk_mul_f16 %0, %0, %1" : "+v"(hp[i]) : "v"(hxy));
+      if (MODE == 17) asm volatile("v_pk_add_f16 %0, %0, %1" : "+v"(hp[i]) : "v"(hxy));
+      if (MODE == 18) {   // float multiply-add, unfused: a product into a temporary, one add into the accumulator
+        float s0;
+        asm volatile("v_mul_f32 %0, %1, %2" : "=v"(s0) : "v"(x), "v"(a[(i + 1) & 15]));
+        asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[i]) : "v"(s0));
+      }
+      if (MODE == 19) {   // the same packed: two elements per lane and instruction
+        f2 s0;
+        asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(s0) : "v"(xy), "v"(p[(i + 1) & 7]));
+        asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p[i & 7]) : "v"(s0));
+      }
+      if (MODE == 20) {   // half: binary16 product, binary16 sum, two elements per lane and instruction
+        h2 s0;
+        asm volatile("v_pk_mul_f16 %0, %1, %2" : "=v"(s0) : "v"(hxy), "v"(hp[(i + 1) & 15]));
+        asm volatile("v_pk_add_f16 %0, %0, %1" : "+v"(hp[i]) : "v"(s0));
+      }
+      if (MODE == 21) {   // double
+        double s0;
+        asm volatile("v_mul_f64 %0, %1, %2" : "=v"(s0) : "v"(dx), "v"(da[(i + 1) & 15]));
+        asm volatile("v_add_f64 %0, %0, %1" : "+v"(da[i]) : "v"(s0));
       }
       // the float min-plus inner loop as valu_tile compiles it: per accumulator and pair of k-steps
       // two adds into temporaries and ONE v_min3 (acc, s0, s1): 3 instructions per 4 operations
@@ -75,6 +103,8 @@ __global__ __launch_bounds__(1024) void k(float *out, unsigned long long *cyc, f
   for (int i = 0; i < 16; ++i) s += a[i];
   for (int i = 0; i < 8; ++i) s += p[i][0] + p[i][1];
   for (int i = 0; i < 16; ++i) s += (float)da[i];
+  for (int i = 0; i < 16; ++i) s += (float)hp[i][0] + (float)hp[i][1];
+  (void)dy;
   out[blockIdx.x * 1024 + threadIdx.x] = s;
   if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 16 + (threadIdx.x >> 6)] = t1 - t0;
 }
@@ -133,6 +163,14 @@ int main() {
     run<11>("v_add_f64", 1, 0, wps, d, dc);
     run<12>("v_min_f64", 1, 0, wps, d, dc);
     run<13>("fp64 min-plus: v_add_f64 + v_min_f64", 2, 2, wps, d, dc);
+    run<14>("v_mul_f32", 1, 0, wps, d, dc);
+    run<15>("v_pk_mul_f32", 1, 0, wps, d, dc);
+    run<16>("v_pk_mul_f16", 1, 0, wps, d, dc);
+    run<17>("v_pk_add_f16", 1, 0, wps, d, dc);
+    run<18>("unfused mul-add f32: v_mul + v_add", 2, 2, wps, d, dc);
+    run<19>("unfused mul-add f32 packed: v_pk_mul + v_pk_add", 2, 4, wps, d, dc);
+    run<20>("unfused mul-add f16 packed: v_pk_mul_f16 + v_pk_add_f16", 2, 4, wps, d, dc);
+    run<21>("unfused mul-add f64: v_mul_f64 + v_add_f64", 2, 2, wps, d, dc);
   }
   return 0;
 }
