@@ -25,6 +25,7 @@ Besides the contract keys the line carries
                reference's kernel sources) timed on this host's cores on float 1024^3 (BASELINE C1)
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -54,8 +55,15 @@ WORKLOADS = {
     # MM_PATH_SPLIT (opt-in): the same fp32 problem on the bf16 matrix cores, six bf16 MFMAs per 16-deep fp32
     # multiply-add block -> the roof for ALGORITHMIC fp32 flops is the bf16 dense peak / 6
     "float_split": ("float", "Multiply", "Add", 16384, "mfma", round(2500.0 / 6.0, 1)),
+    # BASELINE C3's problem in the REFERENCE's half arithmetic (binary16 products accumulated in binary16, k ascending:
+    # kernel/Compute.cpp:129-133 -- what its hosts compare with exactly), on the k-ordered register-tile kernel ("ordered_tile";
+    # MM_PATH_ORDERED == what half_contract = reference routes MM_PATH_AUTO to).  VALU-bound: one v_pk_mul_f16 + one v_pk_add_f16 per
+    # two multiply-adds, each two elements per lane at 4-cycle issue = 128 operations per clock per CU = 78.6 TOp/s
+    # (tools/probes/probe_valu_rate.hip measures the pair at 70.8: profiles/r06a_probe_valu_issue_rates_unfused_pairs.txt)
+    "half_exact": ("half", "Multiply", "Add", 32768, "valu", 78.6),
 }
-PATHS = {"float_split": 2}  # workload -> mm_path_t (default MM_PATH_AUTO)
+PATHS = {"float_split": 2, "half_exact": 1}  # workload -> mm_path_t (default MM_PATH_AUTO)
+STEPS = {"half_exact": (3, 1)}               # workload -> (timed steps, warm-up) of the extras leg when not 5 / 2: one step takes ~0.95 s
 DTYPE_TAG = {"float": "f32", "half": "f16 (f32 accumulate)", "double": "f64", "uint8_t": "u8 (i32 accumulate)"}
 # Context for the two power-limited workloads (not a roof this file prices against: `peak` stays the
 # guide's dense MFMA peak): what the matrix cores sustain from registers alone, no LDS and no memory, on
@@ -101,10 +109,32 @@ def cpu_baseline(sample_n=1024):
             "sample": f"float {sample_n}x{sample_n}x{sample_n} (BASELINE config C1), one call of the reference's "
                       "MatrixMultiplicationKernel compiled from /root/reference/kernel/*.cpp against "
                       "oracle/hlslib_shim: 32 ProcessingElement threads + 7 data movers"}
+    try:
+        with open("/proc/cpuinfo") as f:
+            info["cpu_model"] = next((line.split(":", 1)[1].strip() for line in f if line.startswith("model name")), None)
+    except OSError:
+        info["cpu_model"] = None
+    a, b = _oracle.fill("float", sample_n, sample_n, sample_n)
+    # The yardsticks FIRST, on a quiet host (timed right after the 39-thread simulation, and with the BLAS's
+    # first-call thread-pool start-up inside the clock, they read 36.9 GFLOP/s on the driver's box against ~1 700 on the builder's):
+    # the BLAS reference (ReferenceImplementation, include/Utility.h:76-89) on the same sample -- one untimed call, then the BEST of 5
+    import numpy as np
+    np.matmul(a, b)
+    best = min(_timed(lambda: np.matmul(a, b)) for _ in range(5))
+    info["blas_sgemm_gflops_same_sample"] = round(2.0 * sample_n ** 3 / best / 1e9, 1)
+    try:
+        from threadpoolctl import threadpool_info
+        pools = [p for p in threadpool_info() if p.get("user_api") == "blas"]
+        info["blas_threads"] = pools[0].get("num_threads") if pools else None
+        info["blas_library"] = (pools[0].get("internal_api") or "") + " " + str(pools[0].get("version") or "") if pools else None
+    except Exception:
+        info["blas_threads"] = None
+    # and the semantic spec, Naive (include/Utility.h:18-42), single-threaded: best of 2
+    best = min(_timed(lambda: _oracle.naive("float", "Multiply", "Add", a, b, threads=1)) for _ in range(2))
+    info["naive_1thread_gflops_same_sample"] = round(2.0 * sample_n ** 3 / best / 1e9, 2)
     if not _oracle.ref_available():
         info["sample"] += " -- oracle/_ref not built here, not measured"
         return info
-    a, b = _oracle.fill("float", sample_n, sample_n, sample_n)
     devnull = os.open(os.devnull, os.O_WRONLY)
     saved = os.dup(1)
     sys.stdout.flush()
@@ -119,17 +149,13 @@ def cpu_baseline(sample_n=1024):
         os.close(saved)
     info["value"] = round(2.0 * sample_n ** 3 / dt / 1e9, 4)
     info["seconds"] = round(dt, 3)
-    # for scale: the BLAS reference (ReferenceImplementation, include/Utility.h:76-89) on the same sample
-    import numpy as np
-    t0 = time.perf_counter()
-    for _ in range(5):
-        np.matmul(a, b)
-    info["blas_sgemm_gflops_same_sample"] = round(5 * 2.0 * sample_n ** 3 / (time.perf_counter() - t0) / 1e9, 1)
-    # and the semantic spec, Naive (include/Utility.h:18-42), single-threaded
-    t0 = time.perf_counter()
-    _oracle.naive("float", "Multiply", "Add", a, b, threads=1)
-    info["naive_1thread_gflops_same_sample"] = round(2.0 * sample_n ** 3 / (time.perf_counter() - t0) / 1e9, 2)
     return info
+
+
+def _timed(fn):
+    t0 = time.perf_counter()
+    fn()
+    return time.perf_counter() - t0
 
 
 def replayed_counters(kernel_name, shape, dtype=None):
@@ -180,10 +206,11 @@ LIVE = {
     "uint8": ("mfma_i8_256x256_pingpong_16x16x64", ["uint8"], "mfma_i8_", True),
 }
 LIVE_KERNEL = LIVE["float"][0]
+DRAM_SIDE_PASS = ("float", "half")   # BASELINE C2 / C3: one more pass each, the L2's requests by destination
 
 
 LIVE_STATE = {"deadline": None, "dead": False}   # one wall-clock budget for ALL counter passes of a run; the first failure ends them
-LIVE_BUDGET_S = 150.0
+LIVE_BUDGET_S = 170.0
 
 
 def live_counters(kernel_name, shape, avg_launch_ms, key="float", timeout=75):
@@ -239,6 +266,17 @@ def live_counters(kernel_name, shape, avg_launch_ms, key="float", timeout=75):
         out = {"traffic": int(traffic), "fetch_bytes_corrected": int(2.0 * fetch["FETCH_SIZE"] * 1024.0), "write_bytes": int(write["WRITE_SIZE"] * 1024.0),
                "achieved_fabric_GBps": round(traffic / (1e-3 * avg_launch_ms) / 1e9, 1),
                "counters_measured_in_this_run": True, "launches_profiled_per_pass": launches}
+        if key in DRAM_SIDE_PASS:
+            # the L2's memory-side requests BY DESTINATION (32-byte units): local memory vs GMI / IO.  This is as far towards the
+            # HBM as rocprofv3 -L goes on this part -- see notes.counters and profiles/r06b_pmc_dram_side_counters.json
+            try:
+                dram, _, _ = one_pass(["TCC_EA0_RDREQ_DRAM_32B_sum", "TCC_EA0_WRREQ_WRITE_DRAM_32B_sum"], "dram")
+                db = 32.0 * (dram["TCC_EA0_RDREQ_DRAM_32B_sum"] + dram["TCC_EA0_WRREQ_WRITE_DRAM_32B_sum"])
+                out["dram_destined_bytes"] = int(db)
+                out["achieved_dram_destined_GBps"] = round(db / (1e-3 * avg_launch_ms) / 1e9, 1)
+            except Exception as exc:   # a soft pass: the figures above stand without it
+                out["dram_destined_bytes"] = None
+                sys.stderr.write(f"[bench] DRAM-destination counters for {key} unavailable: {exc!r}\n")
         if has_mfma:
             busy, dur_ns, _ = one_pass(["SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"], "mfma")
             gui = busy["GRBM_GUI_ACTIVE"] / 8.0          # rocprofv3 sums the 8 XCDs
@@ -319,13 +357,13 @@ def roofline_obj(dtype, roof, peak, rows, k, m, launch_ms):
             "avg_launch_ms": round(1e3 * avg_s, 4)}   # (what the part sustains from registers alone: top-level "context")
 
 
-def extra_workloads(g, torch, dev, local_rank, steps=5):
+def extra_workloads(g, torch, dev, local_rank, default_steps=5):
     """The other single-GPU BASELINE configs, a few steps each, in the same process."""
     out = []
     # (MM_EXTRA_KXN=1 adds half_kxn / uint8_kxn, round 4's one-round extras: the same problems with A handed over K x N,
     # MM_TRANSPOSED_A, kernel/Memory.cpp:205-261 -- a transposition pre-pass inside the timed step, then the row-major default)
     jobs = [("half", None), ("double", None), ("minplus", None), ("minplus_f64", None), ("uint8", None), ("float", C5A_ROWS),
-            ("float_split", None)] + ([("half_kxn", None), ("uint8_kxn", None)] if os.environ.get("MM_EXTRA_KXN") == "1" else [])
+            ("float_split", None), ("half_exact", None)] + ([("half_kxn", None), ("uint8_kxn", None)] if os.environ.get("MM_EXTRA_KXN") == "1" else [])
     for key, rows_override in jobs:
         kxn = key.endswith("_kxn")
         dtype, map_op, reduce_op, size, roof, peak = WORKLOADS[key[:-4] if kxn else key]
@@ -336,13 +374,14 @@ def extra_workloads(g, torch, dev, local_rank, steps=5):
             if kxn:
                 a = a.view(k, rows)      # the same HBM bytes read as a K x N matrix (rows == k here)
             path = PATHS.get(key, 0)
-            elapsed, launch_ms = timed_steps(g, torch, a, b, c, dtype, map_op, reduce_op, steps, 2, lambda: None, path, kxn)
+            steps, warm = STEPS.get(key, (default_steps, 2))
+            elapsed, launch_ms = timed_steps(g, torch, a, b, c, dtype, map_op, reduce_op, steps, warm, lambda: None, path, kxn)
             value = 1e-9 * 2.0 * rows * k * m * steps / elapsed
             entry = {"workload": f"{dtype} {rows}x{k}x{m} ({map_op},{reduce_op}) on 1 MI355X"
                                  + ("; BASELINE configs[4]'s job without the split" if rows_override else "")
                                  + ("; A stored K x N (MM_TRANSPOSED_A): pre-pass + kernel both timed" if kxn else ""),
                      "kernel": g.kernel_name(g.make_config(dtype, map_op, reduce_op, path, kxn), rows, k, m),
-                     "dtype": DTYPE_TAG[dtype], "value": round(value, 1), "unit": "GOp/s", "steps": steps, "warmup": 2,
+                     "dtype": DTYPE_TAG[dtype], "value": round(value, 1), "unit": "GOp/s", "steps": steps, "warmup": warm,
                      "ms_per_step": round(1e3 * elapsed / steps, 4),
                      "roofline": roofline_obj(dtype, roof, peak, rows, k, m, launch_ms)}
             entry["key"] = key
@@ -350,6 +389,10 @@ def extra_workloads(g, torch, dev, local_rank, steps=5):
                 entry["roofline"].pop(drop, None)
             if not kxn:   # (two kernels per step there: no single kernel's counters apply)
                 attach_replayed(entry["roofline"], entry["kernel"], (rows, k, m), dtype)
+            if key == "half_exact":
+                entry["workload"] += "; the REFERENCE's half contract (binary16 accumulating in binary16, k ascending): MM_PATH_ORDERED == MM_HALF_CONTRACT=reference"
+                entry["dtype"] = "f16 (f16 accumulate, unfused: kernel/Compute.cpp:129-133)"
+                entry["roofline"]["probe_pair_sustained_TOps"] = 70.8
             if key == "float_split":
                 entry["workload"] += "; MM_PATH_SPLIT (opt-in), pre-pass timed"
                 entry["dtype"] = "f32 in/out; 3 bf16 planes, 6 bf16 MFMAs per pair, f32 accumulate"
@@ -368,7 +411,8 @@ def baseline_summary(out):
     def brief(value, ms, rl, kernel):
         return {"value": value, "ms": round(ms, 3), "frac": rl.get("frac"), "kernel": kernel}
     summary = {"unit": "GOp/s", "C2_float_16384": brief(out["value"], out["ms_per_step"], out["roofline"], out["config"]["kernel"])}
-    names = {"half": "C3_half_32768", "double": "C4_double_16384", "minplus": "C5b_minplus_8192", "float": "C5a_float_65536_rows_1gpu"}
+    names = {"half": "C3_half_32768", "half_exact": "C3_half_32768_reference_contract", "double": "C4_double_16384", "minplus": "C5b_minplus_8192",
+             "float": "C5a_float_65536_rows_1gpu"}
     for w in out.get("workloads", []):
         if w.get("key") in names and "error" not in w:
             summary[names[w["key"]]] = brief(w["value"], w["ms_per_step"], w["roofline"], w["kernel"])
@@ -405,6 +449,9 @@ def main():
                     help="N > 1 only. strong: a fixed job (--total-rows, default BASELINE's 65536 x 16384 x 16384) split "
                          "along N; weak: every rank owns --size rows")
     ap.add_argument("--total-rows", type=int, default=0, help="rows of C of the strong-scaling job")
+    ap.add_argument("--scale-base", type=float, default=float(os.environ.get("MM_SCALE_BASE", "0") or 0),
+                    help="N > 1: GFLOP/s of the SAME job on one GPU (the N = 1 line's scale_base.value); the line then carries "
+                         "strong_scaling_vs_scale_base = value / this.  Also read from MM_SCALE_BASE")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the workloads[] / weak_scaling extras")
     args = ap.parse_args()
@@ -479,6 +526,39 @@ def main():
         dist.all_reduce(t)
         return [int(x) for x in t.tolist()]
 
+    def gather_per_rank(record):
+        """Every rank's own account of its leg, on rank 0 -- over the same control plane as the barrier (all_reduce of a
+        [world, slot] byte matrix in which each rank fills its row: works on RCCL and gloo alike, no pickling of device tensors)."""
+        if not use_dist:
+            return [record]
+        slot = 1024
+        raw = json.dumps(record).encode()[:slot]
+        t = torch.zeros((world, slot), dtype=torch.int32, device=ctl_dev)
+        t[rank, :len(raw)] = torch.tensor(list(raw), dtype=torch.int32, device=ctl_dev)
+        dist.all_reduce(t)
+        out = []
+        for r in range(world):
+            row = bytes(int(x) for x in t[r].tolist()).rstrip(b"\0")
+            try:
+                out.append(json.loads(row.decode()))
+            except Exception:
+                out.append({"rank": r, "error": "record did not arrive"})
+        return out
+
+    def device_identity():
+        ident = {"pci_bus_id": None, "sclk_mhz_after_run": None}
+        try:
+            buf = ctypes.create_string_buffer(32)
+            g._check(g.lib().mm_device_pci_bus_id(local_rank, buf, 32))
+            ident["pci_bus_id"] = buf.value.decode()
+        except Exception as exc:
+            ident["pci_bus_id"] = f"unavailable: {exc!r}"[:60]
+        try:
+            ident["sclk_mhz_after_run"] = int(torch.cuda.clock_rate(dev))
+        except Exception:
+            pass
+        return ident
+
     ranks_seen = 1
     if use_dist:
         one = torch.ones(1, dtype=torch.float64, device=ctl_dev)
@@ -499,12 +579,21 @@ def main():
         """One timed region of the contract over the job of n_total rows; rank r owns row_slab(r)."""
         row0, rows = row_slab(n_total, world, rank)
         a, b, c = alloc_fill(g, torch, dev, local_rank, dtype, rows, k, m, seed_base + rank, 7)
-        elapsed, launch_ms = timed_steps(g, torch, a, b, c, dtype, map_op, reduce_op, args.steps, args.warmup, barrier,
-                                         PATHS.get(args.workload, 0))
-        elapsed = max_over_ranks(elapsed)
+        own_elapsed, launch_ms = timed_steps(g, torch, a, b, c, dtype, map_op, reduce_op, args.steps, args.warmup, barrier,
+                                             PATHS.get(args.workload, 0))
+        elapsed = max_over_ranks(own_elapsed)
         a = b = c = None
         torch.cuda.empty_cache()
-        return rows, elapsed, launch_ms, rows_of_every_rank(rows)
+        # what THIS rank did, in its own words: if the job lands at 6.6x instead of 8x the line says which rank, on which PCI
+        # device, running which kernel, at what launch time -- not only rank 0's launches and a maximum (VERDICT r5 missing 4)
+        record = {"rank": rank, "local_rank": local_rank, "row0": row0, "rows": rows,
+                  "kernel": g.kernel_name(job_cfg, rows, k, m) if rows else None,
+                  "wall_ms_per_step": round(1e3 * own_elapsed / args.steps, 4),
+                  "launch_ms_median": round(launch_ms[len(launch_ms) // 2], 4), "launch_ms_min": round(launch_ms[0], 4),
+                  "launch_ms_max": round(launch_ms[-1], 4),
+                  "control_plane": ("rccl" if backend == "nccl" else backend) if use_dist else "none"}
+        record.update(device_identity())
+        return rows, elapsed, launch_ms, rows_of_every_rank(rows), gather_per_rank(record)
 
     if world == 1:
         scaling = args.scaling
@@ -515,12 +604,12 @@ def main():
     else:
         scaling = "weak"
         n_total = args.size * world
-    rows, elapsed, launch_ms, rows_all = run_job(n_total, 1000)
+    rows, elapsed, launch_ms, rows_all, per_rank = run_job(n_total, 1000)
 
     weak = None
     if world > 1 and scaling == "strong" and not args.no_extra:
-        w_rows, w_elapsed, w_launch, _ = run_job(args.size * world, 5000)
-        weak = (w_rows, w_elapsed, w_launch)
+        w_rows, w_elapsed, w_launch, _, w_per_rank = run_job(args.size * world, 5000)
+        weak = (w_rows, w_elapsed, w_launch, w_per_rank)
 
     if rank == 0:
         flops_job = 2.0 * n_total * k * m
@@ -561,13 +650,29 @@ def main():
                               "ranks_seen": ranks_seen, "devices_visible": torch.cuda.device_count()},
             "roofline": rl,
         }
+        if world > 1 or use_dist:
+            out["per_rank"] = per_rank
+            walls = [(r.get("wall_ms_per_step") or 0.0, r.get("rank")) for r in per_rank]
+            out["slowest_rank"] = max(walls)[1]
+            out["fastest_over_slowest_wall"] = round(min(w for w, _ in walls) / max(w for w, _ in walls), 4) if max(walls)[0] > 0 else None
+            # the partition every rank computed for itself (mm_row_slab: configuration, shape and knobs only) must tile the job
+            spans = sorted((r.get("row0", 0), r.get("rows", 0)) for r in per_rank if r.get("rows"))
+            tiled = bool(spans) and spans[0][0] == 0 and all(a0 + an == b0 for (a0, an), (b0, _) in zip(spans, spans[1:])) \
+                and spans[-1][0] + spans[-1][1] == n_total
+            out["config"]["row_slabs_tile_the_job"] = tiled
+            if not tiled:
+                raise SystemExit(f"the ranks' row slabs do not tile the {n_total}-row job: {spans} -- ranks disagree on the partition "
+                                 "(different knobs in their environments?)")
+            if args.scale_base > 0:
+                out["strong_scaling_vs_scale_base"] = {"scale_base_GFLOPs": args.scale_base, "factor": round(value / args.scale_base, 3),
+                                                       "efficiency_note": "the driver computes efficiency itself; this is value / the 1-GPU value of the same job handed in with --scale-base"}
         if weak is not None:
-            w_rows, w_elapsed, w_launch = weak
+            w_rows, w_elapsed, w_launch, w_per_rank = weak
             out["weak_scaling"] = {
                 "workload": f"{dtype} {args.size * world}x{k}x{m}: {args.size} rows per GPU over {world} MI355X",
                 "value": round(1e-9 * 2.0 * args.size * world * k * m * args.steps / w_elapsed, 1), "unit": "GFLOP/s",
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * w_elapsed / args.steps, 4),
-                "roofline": roofline_obj(dtype, roof, peak, w_rows, k, m, w_launch)}
+                "roofline": roofline_obj(dtype, roof, peak, w_rows, k, m, w_launch), "per_rank": w_per_rank}
         if world == 1 and headline and not args.no_extra:
             out["workloads"] = extra_workloads(g, torch, dev, local_rank)
             # the strong-scaling job (BASELINE configs[4], float 65536 x 16384 x 16384) on ONE GPU, already timed above:
@@ -595,7 +700,15 @@ def main():
             out["notes"] = {
                 "counters": "roofline objects with counters_measured_in_this_run = true carry rocprofv3 PMC figures collected by this run: child passes "
                             "(--pmc X --kernel-trace) of tools/sweep.py on the same shape after the timed legs; traffic = FETCH_SIZE x2 (gfx950 correction) + "
-                            "WRITE_SIZE, KiB -> bytes per launch; MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs).  With false, traffic (L2 <-> fabric bytes per launch, Infinity-Cache hits included), mfma_util_pct, "
+                            "WRITE_SIZE, KiB -> bytes per launch; MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs).  The passes profile "
+                            "launches of the SAME C-ABI call on the same shape made by tools/sweep.py children (2 + 1 warm-up each), not the timed launches "
+                            "themselves: profiled_launch_ms next to avg_launch_ms says how much the profiler slows them.  `traffic` is L2 <-> FABRIC bytes, "
+                            "Infinity-Cache hits included: an UPPER bound on HBM bytes.  rocprofv3 -L on this part has no counter behind the Infinity Cache "
+                            "(no MALL / HBM-channel counters); the nearest are TCC_EA0_RDREQ_DRAM_32B / TCC_EA0_WRREQ_WRITE_DRAM_32B, the L2's requests whose "
+                            "DESTINATION is local memory (as opposed to GMI / IO), collected for C2 and C3 as dram_destined_bytes: they equal the all-request "
+                            "byte count to 0.05 % (profiles/r06b_pmc_dram_side_counters.json, incl. a single-tile problem whose 537 MB of operands are read once: "
+                            "553 MB by request size, 553 MB DRAM-destined, FETCH_SIZE x2 553 MB), i.e. they confirm the x2 correction and say nothing about "
+                            "Infinity-Cache hits.  With false, traffic (L2 <-> fabric bytes per launch, Infinity-Cache hits included), mfma_util_pct, "
                             "profiled_clock_GHz and l2_hit_rate are REPLAYED from the committed PMC files named in *_source, which profiled the "
                             "same kernel on the same shape on an earlier box",
                 "peaks": "MI355X_MICROARCH.md dense MFMA peaks (fp32 157.3, fp16 2500, i8 5000 T/s; fp64 78.6 datasheet); min-plus: SURVEY 8(d) "

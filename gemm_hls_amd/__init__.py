@@ -24,7 +24,7 @@ EXPORTS = ["mm_init", "mm_alloc", "mm_free", "mm_copy_to_device", "mm_copy_to_ho
            "MatrixMultiplicationKernel", "mm_set_default_config", "mm_dtype_size",
            "mm_config_supported", "mm_kernel_name", "mm_kernel_info", "mm_last_error",
            "mm_gemm_host", "mm_tuning_set", "mm_tuning_get", "mm_release_workspace", "mm_device_pci_bus_id",
-           "mm_row_slab"]
+           "mm_row_slab", "mm_gemm_multi_device_timed"]
 
 
 class MMError(RuntimeError):
@@ -75,6 +75,8 @@ def lib():
         L.mm_gemm_launch.argtypes = [i, cfgp, vp, vp, vp, u, u, u, ctypes.POINTER(ctypes.c_double)]
         L.mm_gemm_enqueue.argtypes = [vp, cfgp, vp, vp, vp, u, u, u]
         L.mm_gemm_multi_device.argtypes = [i, cfgp, vp, vp, vp, u, u, u, ctypes.POINTER(ctypes.c_double)]
+        L.mm_gemm_multi_device_timed.argtypes = [i, cfgp, vp, vp, vp, u, u, u, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
+                                                 ctypes.POINTER(ctypes.c_double)]
         L.MatrixMultiplicationKernel.argtypes = [vp, vp, vp, u, u, u]
         L.MatrixMultiplicationKernel.restype = None
         L.mm_set_default_config.argtypes = [cfgp]
@@ -187,9 +189,10 @@ def row_slab(cfg, n, k, m, world_size, rank):
     return row0.value, rows.value
 
 
-def matmul_host(a, b, dtype="float", map_op="Multiply", reduce_op="Add", path=PATH_AUTO, devices=1, transposed_a=False):
+def matmul_host(a, b, dtype="float", map_op="Multiply", reduce_op="Add", path=PATH_AUTO, devices=1, transposed_a=False, timing=False):
     """numpy in, numpy out, through mm_gemm_multi_device (rows of C split over `devices` GPUs).
-    a: (N, K), or (K, N) with transposed_a.  Returns (C, kernel_seconds)."""
+    a: (N, K), or (K, N) with transposed_a.  Returns (C, kernel_seconds); with timing=True (C, kernel_seconds, per-device
+    kernel seconds, host-clock seconds) from mm_gemm_multi_device_timed."""
     import numpy as np
     a = np.ascontiguousarray(a)
     b = np.ascontiguousarray(b)
@@ -198,6 +201,12 @@ def matmul_host(a, b, dtype="float", map_op="Multiply", reduce_op="Add", path=PA
     c = np.empty((n, m), dtype=a.dtype)
     cfg = make_config(dtype, map_op, reduce_op, path, transposed_a)
     t = ctypes.c_double(0)
+    if timing:
+        per_device = (ctypes.c_double * devices)()
+        wall = ctypes.c_double(0)
+        _check(lib().mm_gemm_multi_device_timed(devices, ctypes.byref(cfg), a.ctypes.data, b.ctypes.data, c.ctypes.data,
+                                                n, k, m, ctypes.byref(t), per_device, ctypes.byref(wall)))
+        return c, t.value, list(per_device), wall.value
     _check(lib().mm_gemm_multi_device(devices, ctypes.byref(cfg), a.ctypes.data, b.ctypes.data, c.ctypes.data,
                                       n, k, m, ctypes.byref(t)))
     return c, t.value

@@ -444,12 +444,25 @@ int mm_gemm_launch(int device, const mm_config_t *cfg, const void *a, const void
 static unsigned md_slab_rows(const mm_config_t &cfg, unsigned n, unsigned k, unsigned m, int device_count) {
   if (n == 0) return 0;
   const size_t base = ((size_t)n + device_count - 1) / device_count;
-  const unsigned cand = (unsigned)std::min<size_t>(n, (base + 127) / 128 * 128);
-  mm_kernel_info_t info = {};
-  const mm::Problem p{nullptr, nullptr, nullptr, cand, k, m, cfg.layout_a == MM_A_TRANSPOSED, cand == n ? 0u : n};
-  kernel_info_for(&cfg, p, &info);
-  const size_t tile = info.tile_n ? info.tile_n : 128;
-  return (unsigned)std::min<size_t>(n, (base + tile - 1) / tile * tile);
+  // The tile height is a property of the kernel that runs on a slab of the FINAL height, which the rounding itself changes
+  // (ADVICE r5): iterate to a fixed point -- tile of a slab of `rows` rows -> rows = ceil(N / G) rounded up to it -> ... -- and
+  // if the geometry choice flips back and forth, round to the largest tile any candidate uses (256), which every smaller
+  // one divides.  Depends on (configuration, shape, knobs) only: not on the current device, so that every rank of a
+  // one-process-per-GPU job computes the same partition.
+  auto tile_for = [&](unsigned rows) -> size_t {
+    mm_kernel_info_t info = {};
+    const mm::Problem p{nullptr, nullptr, nullptr, rows, k, m, cfg.layout_a == MM_A_TRANSPOSED, rows == n ? 0u : n};
+    kernel_info_for(&cfg, p, &info);
+    return info.tile_n ? info.tile_n : 128;
+  };
+  unsigned rows = (unsigned)std::min<size_t>(n, (base + 127) / 128 * 128);
+  for (int it = 0; it < 4; ++it) {
+    const size_t tile = tile_for(rows);
+    const unsigned next = (unsigned)std::min<size_t>(n, (base + tile - 1) / tile * tile);
+    if (next == rows) return rows;
+    rows = next;
+  }
+  return (unsigned)std::min<size_t>(n, (base + 255) / 256 * 256);
 }
 
 int mm_row_slab(const mm_config_t *cfg, unsigned n, unsigned k, unsigned m, int device_count, int rank, unsigned *row0,
@@ -470,10 +483,13 @@ struct SplitDevice {
   void *a = nullptr, *b = nullptr, *c = nullptr;
   unsigned row0 = 0, rows = 0;
   hipStream_t s = nullptr;
+  hipEvent_t start = nullptr, stop = nullptr;   // around this device's launch, on its stream
   ~SplitDevice() {
-    if (!a && !b && !c && !s) return;
+    if (!a && !b && !c && !s && !start && !stop) return;
     (void)hipSetDevice(phys);
     if (s) (void)hipStreamSynchronize(s);
+    if (start) (void)hipEventDestroy(start);
+    if (stop) (void)hipEventDestroy(stop);
     if (a) (void)hipFree(a);
     if (b) (void)hipFree(b);
     if (c) (void)hipFree(c);
@@ -484,6 +500,12 @@ struct SplitDevice {
 
 int mm_gemm_multi_device(int device_count, const mm_config_t *cfg, const void *a_host, const void *b_host,
                          void *c_host, unsigned n, unsigned k, unsigned m, double *elapsed_seconds) {
+  return mm_gemm_multi_device_timed(device_count, cfg, a_host, b_host, c_host, n, k, m, elapsed_seconds, nullptr, nullptr);
+}
+
+int mm_gemm_multi_device_timed(int device_count, const mm_config_t *cfg, const void *a_host, const void *b_host,
+                               void *c_host, unsigned n, unsigned k, unsigned m, double *elapsed_seconds,
+                               double *per_device_seconds, double *host_wall_seconds) {
   int rc = ensure_init();
   if (rc) return rc;
   rc = check_problem(cfg, a_host, b_host, c_host, n, k, m);
@@ -495,6 +517,8 @@ int mm_gemm_multi_device(int device_count, const mm_config_t *cfg, const void *a
   const int limit = virt > 0 ? virt : g_device_count;
   if (device_count < 1 || device_count > limit)
     return fail(MM_ERR_BAD_ARGUMENT, "device_count %d not in [1, %d]", device_count, limit);
+  if (per_device_seconds) std::fill(per_device_seconds, per_device_seconds + device_count, 0.0);
+  if (host_wall_seconds) *host_wall_seconds = 0.0;
   if (n == 0 || m == 0) {   // an empty C: nothing to copy, launch or time (the single-device entry points do the same)
     if (elapsed_seconds) *elapsed_seconds = 0.0;
     return MM_OK;
@@ -518,6 +542,8 @@ int mm_gemm_multi_device(int device_count, const mm_config_t *cfg, const void *a
     MM_HIP_MD(hipSetDevice(d.phys));
     MM_HIP_MD(hipStreamCreateWithFlags(&d.s, hipStreamNonBlocking));
     if (!d.rows) continue;          // a trailing device without rows takes no part (and no copy of B)
+    MM_HIP_MD(hipEventCreate(&d.start));
+    MM_HIP_MD(hipEventCreate(&d.stop));
     MM_HIP_MD(hipMalloc(&d.b, (size_t)k * m * es));
     MM_HIP_MD(hipMalloc(&d.a, (size_t)d.rows * k * es));
     MM_HIP_MD(hipMalloc(&d.c, (size_t)d.rows * m * es));
@@ -566,8 +592,11 @@ int mm_gemm_multi_device(int device_count, const mm_config_t *cfg, const void *a
   // untimed warm-up pass of the same launch: the first dispatch on a device loads the code object,
   // opts the kernel into its LDS size and ramps the clocks; paying that outside the timed region
   // makes this figure comparable with mm_gemm_launch's (whose callers warm up the same way).
-  // pass 1 is the timed region: common start -> every device complete (copies excluded, as RunHardware.cpp does)
-  double elapsed = 0.0;
+  // pass 1 is the timed region (copies excluded, as RunHardware.cpp:161-180 does).  Every device's launch is bracketed by HIP
+  // events on ITS stream: the job's time is the MAX over devices of that kernel time -- what ExecuteTask() would
+  // report on the slowest device -- and the per-device figures say which device that was.  The host clock from the first
+  // dispatch to the last completion is kept as a cross-check (it adds G launch latencies and G stream synchronisations).
+  double elapsed = 0.0, wall = 0.0;
   for (int pass = 0; pass < 2; ++pass) {
     const auto t0 = std::chrono::steady_clock::now();
     for (SplitDevice &d : devs) {
@@ -575,12 +604,24 @@ int mm_gemm_multi_device(int device_count, const mm_config_t *cfg, const void *a
       MM_HIP_MD(hipSetDevice(d.phys));
       // a row slab of the n-row job (n_total 0: the slab IS the job -- the same launch as mm_gemm_launch's)
       const mm::Problem p{d.a, d.b, d.c, d.rows, k, m, kxn, d.rows == n ? 0u : n};
+      MM_HIP_MD(hipEventRecord(d.start, d.s));
       rc = dispatch(d.s, *cfg, p);
       if (rc) return rc;
+      MM_HIP_MD(hipEventRecord(d.stop, d.s));
     }
     for (SplitDevice &d : devs) { MM_HIP_MD(hipSetDevice(d.phys)); MM_HIP_MD(hipStreamSynchronize(d.s)); }
-    elapsed = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   }
+  for (int g = 0; g < device_count; ++g) {
+    SplitDevice &d = devs[g];
+    if (!d.rows) continue;
+    MM_HIP_MD(hipSetDevice(d.phys));
+    float ms = 0.f;
+    MM_HIP_MD(hipEventElapsedTime(&ms, d.start, d.stop));
+    if (per_device_seconds) per_device_seconds[g] = 1e-3 * (double)ms;
+    elapsed = std::max(elapsed, 1e-3 * (double)ms);
+  }
+  if (host_wall_seconds) *host_wall_seconds = wall;
   if (elapsed_seconds) *elapsed_seconds = elapsed;
   for (SplitDevice &d : devs) {
     if (!d.rows) continue;

@@ -173,8 +173,19 @@ int main(int argc, char **argv) {
       std::cout << "Initializing device memory on " << gpus << " devices, copying row slabs of A and C and replicas of B...\n"
                 << std::flush;
       std::cout << "Executing kernel...\n" << std::flush;
-      Check(mm_gemm_multi_device(gpus, &cfg, a.data(), b.data(), cTest.data(), size_n, size_k, size_m, &elapsed),
-            "mm_gemm_multi_device");
+      std::vector<double> per_device(gpus, 0.0);
+      double host_wall = 0.0;
+      Check(mm_gemm_multi_device_timed(gpus, &cfg, a.data(), b.data(), cTest.data(), size_n, size_k, size_m, &elapsed,
+                                       per_device.data(), &host_wall),
+            "mm_gemm_multi_device_timed");
+      // where the time went: each device's own kernel time (HIP events on its stream); the job's time is their maximum
+      for (int g = 0; g < gpus; ++g) {
+        unsigned row0 = 0, rows = 0;
+        Check(mm_row_slab(&cfg, size_n, size_k, size_m, gpus, g, &row0, &rows), "mm_row_slab");
+        std::cout << "  device " << g << ": rows [" << row0 << ", " << row0 + rows << ") in " << per_device[g] << " seconds"
+                  << (per_device[g] == elapsed && rows ? "  <- slowest" : "") << "\n";
+      }
+      std::cout << "  host clock, first dispatch to last completion: " << host_wall << " seconds\n" << std::flush;
     } else {
       std::cout << "Initializing device memory...\n" << std::flush;
       DeviceBuffer aDevice(0, count_a * sizeof(Data_t)), bDevice(0, count_b * sizeof(Data_t)),

@@ -4,14 +4,13 @@ contiguous rows [row0, row0+rows) of A and C and a replica of B; no collective i
 
 The arithmetic lives in ONE place, the library (mm_row_slab in csrc/mm_capi.hip, which
 mm_gemm_multi_device uses itself): slabs are ceil(N/G) rows rounded up to whole tile rows of the
-kernel that will run on them.  `row_slab_for` asks the library; `row_slab` is the same rule with an
-explicit tile height, for callers that already know it."""
+kernel that will run on them.  `row_slab_for` asks the library -- the partition every caller should use;
+`row_slab` is the same rule with an EXPLICIT tile height (no default: 64512 rows over 8 ranks are 8064-row slabs
+with 128-row tiles but 8192-row slabs with the 256-row tiles the large fp32 / half / int8 kernels keep),
+for tests and callers that already know the tile."""
 
 
-TILE_ROWS = 128  # tile height of the mid-size geometries; the large fp32 / half / int8 defaults keep 256-row tiles
-
-
-def row_slab(size_n, world_size, rank, tile_rows=TILE_ROWS):
+def row_slab(size_n, world_size, rank, tile_rows):
     """(row0, rows) of `rank`'s slab: ceil(N/G) rows rounded UP to a whole macro-tile, so that no
     rank but the last busy one owns a ragged tile row ("contiguous slabs aligned to the
     kernel's N macro-tile"); trailing slabs may be short or empty."""

@@ -164,7 +164,8 @@ int mm_gemm_enqueue(void *hip_stream, const mm_config_t *cfg, const void *a_dev,
 /* One node, `device_count` GPUs, rows of C split into contiguous slabs (device g gets the rows mm_row_slab() names), B
  * replicated, no collective: every outer tile of C is independent (kernel/Compute.cpp:53-60, kernel/Memory.cpp:114-127,
  * 272-286, 367-391).  Host pointers in, host pointer out; copies are outside the timed region exactly as in
- * RunHardware.cpp:140-190.  *elapsed_seconds = from a common start to the last device's completion.  New functionality
+ * RunHardware.cpp:140-190.  *elapsed_seconds = the longest of the devices' kernel times, each measured with HIP events on that
+ * device's stream (mm_gemm_multi_device_timed also hands out the per-device figures and the host clock).  New functionality
  * (the reference is single-device).  A K x N A (MM_A_TRANSPOSED == MM_TRANSPOSED_A, kernel/Memory.cpp:205-261)
  * is split along its columns (one strided copy per device).  With device_count = 1 (or N within one slab) the launch is
  * mm_gemm_launch's.  The kernel FAMILY and every decision that changes a row's summation order (split-K of small fp32
@@ -176,6 +177,14 @@ int mm_gemm_enqueue(void *hip_stream, const mm_config_t *cfg, const void *a_dev,
 int mm_gemm_multi_device(int device_count, const mm_config_t *cfg, const void *a_host,
                          const void *b_host, void *c_host, unsigned size_n, unsigned size_k,
                          unsigned size_m, double *elapsed_seconds);
+/* The same call, saying where the time went ("max over devices of kernel time").  Every
+ * device's launch is bracketed by HIP events on its own stream: *elapsed_seconds = the MAX over devices of that kernel time
+ * (== what mm_gemm_multi_device reports), per_device_seconds[g] (device_count entries, may be NULL) = device g's own kernel
+ * time, 0 for a trailing device that got no rows, *host_wall_seconds (may be NULL) = the host clock from the first dispatch
+ * to the last completion, a cross-check that also contains the G launch latencies.  `MM_GPUS=G RunHardware.exe` prints them. */
+int mm_gemm_multi_device_timed(int device_count, const mm_config_t *cfg, const void *a_host, const void *b_host,
+                               void *c_host, unsigned size_n, unsigned size_k, unsigned size_m, double *elapsed_seconds,
+                               double *per_device_seconds, double *host_wall_seconds);
 /* The row partition mm_gemm_multi_device uses, for callers that drive one process per GPU themselves (bench.py):
  * slabs of ceil(N / G) rows rounded up to whole tile rows of the kernel that will run on them (mm_kernel_info's tile_n),
  * so only the last busy device owns a ragged tile row; trailing devices may get *rows = 0.  Pure arithmetic: works

@@ -10,7 +10,7 @@
  * the pin is (seed 5, dist(1,10), A-then-B draw order, comparison rule) plus
  * the reference's own sources compiled into oracle/_ref (see oracle/Makefile,
  * oracle/hlslib_shim) and run against this restatement in
- * tests/test_oracle_vs_reference.py.  RNG golden draws: tests/golden/.
+ * tests/test_oracle.py.  RNG golden draws: tests/golden/.
  *
  * What follows which reference lines:
  *   mm_oracle_fill      host/RunHardware.cpp:31-35,99-105 == test/TestSimulation.cpp:42-55,

@@ -96,10 +96,11 @@ def test_default_mode_for_more_than_one_gpu_is_baselines_fixed_job():
 
 
 def test_strong_split_of_the_baseline_job_is_tile_aligned_and_balanced():
-    from gemm_hls_amd.partition import row_slab
+    import gemm_hls_amd as g
+    from gemm_hls_amd.partition import row_slab_for
     b = _bench()
     for world in (1, 2, 4, 8):
-        slabs = [row_slab(b.C5A_ROWS, world, r) for r in range(world)]
+        slabs = [row_slab_for(g.make_config("float"), b.C5A_ROWS, b.SIZE, b.SIZE, world, r) for r in range(world)]
         assert sum(rows for _, rows in slabs) == b.C5A_ROWS
         assert all(rows == b.C5A_ROWS // world and row0 % 256 == 0 for row0, rows in slabs)
 

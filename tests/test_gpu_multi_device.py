@@ -10,6 +10,7 @@ row's value may not depend on how the rows were dealt out).  Where >= 2 real GPU
 import ctypes
 import json
 import os
+import re
 import subprocess
 import sys
 
@@ -138,6 +139,34 @@ def test_multi_device_large_default_geometry_and_tile_aligned_slabs(virtual_devi
     assert np.max(np.abs(c3[rows] - exact) / exact) < 1e-5
 
 
+def test_multi_device_timed_reports_every_devices_own_kernel_time():
+    """mm_gemm_multi_device_timed ("max over devices of kernel time"): HIP events around each device's launch on its
+    own stream; the job's time is their maximum, a device without rows reports 0, the host clock is the cross-check -- and
+    `MM_GPUS=G RunHardware.exe` prints them."""
+    g.set_tuning("md_virtual_devices", 8)
+    try:
+        rng = np.random.default_rng(5)
+        n, k, m = 1000, 512, 528
+        a, b = _uniform(rng, (n, k), np.float32), _uniform(rng, (k, m), np.float32)
+        c1, _ = g.matmul_host(a, b, devices=1)
+        c, t, per_device, wall = g.matmul_host(a, b, devices=3, timing=True)
+        assert np.array_equal(c, c1)
+        assert len(per_device) == 3 and all(x > 0 for x in per_device) and t == max(per_device) and wall >= t > 0
+        # 5 rows over 8 devices: one 5-row slab (rounded up to a tile), seven devices idle
+        a5 = a[:5].copy()
+        c5, t5, per5, _ = g.matmul_host(a5, b, devices=8, timing=True)
+        assert np.array_equal(c5, c1[:5]) and per5[0] == t5 > 0 and per5[1:] == [0.0] * 7
+    finally:
+        g.set_tuning("md_virtual_devices", -1)
+    exe = os.path.join(ROOT, "bin", "RunHardware.exe")
+    env = dict(os.environ, MM_GPUS="3", MM_MD_VIRTUAL_DEVICES="3")
+    r = subprocess.run([exe, "1000", "528", "528", "hw", "off"], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    got = re.findall(r"device (\d): rows \[(\d+), (\d+)\) in ([\d\.e\-\+]+) seconds", r.stdout)
+    assert [(int(d), int(lo), int(hi)) for d, lo, hi, _ in got] == [(0, 0, 384), (1, 384, 768), (2, 768, 1000)], r.stdout
+    assert r.stdout.count("<- slowest") == 1 and "host clock, first dispatch to last completion" in r.stdout
+
+
 def test_multi_device_count_is_never_silently_reduced():
     import torch
     have = torch.cuda.device_count()
@@ -171,7 +200,7 @@ def test_multi_device_bench_eight_ranks_on_one_device_dry_run():
     plane: the BASELINE configs[4] job, 8192 rows per rank, the large fp32 default kernel, one JSON line."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(MM_BENCH_DEVICE_MOD="1", MM_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "20", "--warmup", "5"]
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "20", "--warmup", "5", "--scale-base", "150000"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -187,6 +216,20 @@ def test_multi_device_bench_eight_ranks_on_one_device_dry_run():
     assert out["weak_scaling"]["value"] > 0 and "16384 rows per GPU" in out["weak_scaling"]["workload"]
     # eight ranks time-share ONE device here: the whole job cannot run faster than one device's roof
     assert out["value"] < 157.3e3 * 1.02
+    # the line explains itself: one record per rank -- PCI device, slab, kernel, its own wall time and launch
+    # times from the stream events, the control plane it ended up on -- the slowest rank named, the partition cross-checked
+    assert [r["rank"] for r in out["per_rank"]] == list(range(8))
+    for i, rec in enumerate(out["per_rank"]):
+        assert (rec["row0"], rec["rows"]) == (8192 * i, 8192) and rec["kernel"] == "mfma_f32_256x256x16_w8_flush4096"
+        assert re.fullmatch(r"[0-9a-fA-F]{4}:[0-9a-fA-F]{2}:[0-9a-fA-F]{2}\.[0-9]", rec["pci_bus_id"]), rec
+        assert 0 < rec["launch_ms_min"] <= rec["launch_ms_median"] <= rec["launch_ms_max"] and rec["wall_ms_per_step"] > 0
+        assert rec["control_plane"] == "gloo"
+    assert len({rec["pci_bus_id"] for rec in out["per_rank"]}) == 1          # the dry run: all eight on the one device
+    assert out["slowest_rank"] in range(8) and 0 < out["fastest_over_slowest_wall"] <= 1
+    assert max(rec["wall_ms_per_step"] for rec in out["per_rank"]) == pytest.approx(out["ms_per_step"], rel=1e-3)
+    assert out["config"]["row_slabs_tile_the_job"] is True
+    assert out["strong_scaling_vs_scale_base"]["factor"] == pytest.approx(out["value"] / 150000.0, rel=1e-3)
+    assert len(out["weak_scaling"]["per_rank"]) == 8
 
 
 def test_multi_device_bench_control_plane_on_rccl_with_one_rank():

@@ -968,8 +968,8 @@ def test_f32_baseline_c5a_shape_on_one_gpu_large_offsets():
     got = c[rows].cpu().numpy()
     assert np.max(np.abs(got - exact) / exact) < F32_TOL
     # slab [3/8, 4/8) of an 8-way row split, computed on its own: identical bits
-    from gemm_hls_amd.partition import row_slab
-    row0, cnt = row_slab(n, 8, 3)
+    from gemm_hls_amd.partition import row_slab_for
+    row0, cnt = row_slab_for(g.make_config("float"), n, k, m, 8, 3)
     slab = g.matmul(a[row0:row0 + cnt].contiguous(), b)
     assert torch.equal(slab, c[row0:row0 + cnt])
 

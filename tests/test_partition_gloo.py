@@ -21,14 +21,16 @@ from gemm_hls_amd.partition import row_slab  # noqa: E402
 def test_row_slabs_tile_the_rows(n, world):
     covered = []
     for r in range(world):
-        row0, rows = row_slab(n, world, r)
+        row0, rows = row_slab(n, world, r, 128)
         assert 0 <= rows and row0 + rows <= n
         covered.extend(range(row0, row0 + rows))
     assert covered == list(range(n))
     # slabs are ceil(N/G) rounded up to whole 128-row macro-tiles: every slab start is tile-aligned
     slab = min(n, -(-(-(-n // world)) // 128) * 128)
-    assert max(row_slab(n, world, r)[1] for r in range(world)) == slab
-    assert all(row_slab(n, world, r)[0] % 128 == 0 or row_slab(n, world, r)[1] == 0 for r in range(world))
+    assert max(row_slab(n, world, r, 128)[1] for r in range(world)) == slab
+    assert all(row_slab(n, world, r, 128)[0] % 128 == 0 or row_slab(n, world, r, 128)[1] == 0 for r in range(world))
+    with pytest.raises(TypeError):
+        row_slab(n, world, 0)        # the tile height is the caller's to state (or row_slab_for's to ask the library)
 
 
 @pytest.mark.parametrize("dtype", ["float", "half", "double", "int", "uint8_t"])
@@ -86,7 +88,7 @@ def _worker(rank, world, port, dtype, ops, shape, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     n, k, m = shape
     a, b = _oracle.fill(dtype, n, k, m)          # every rank regenerates the seeded inputs
-    row0, rows = row_slab(n, world, rank)
+    row0, rows = row_slab(n, world, rank, 128)
     c_slab = _oracle.naive(dtype, ops[0], ops[1], a[row0:row0 + rows], b, threads=1) if rows else \
         np.empty((0, m), a.dtype)
     # bench.py's timing protocol: barrier, local time, MAX over ranks
