@@ -755,6 +755,7 @@ const char *mm_kernel_name(const mm_config_t *cfg, unsigned n, unsigned k, unsig
       if (splits == 0) return "mfma_f32_128x128x32_w4x2_streamk";            // teams, the last part to arrive gathers: what MM_PATH_AUTO runs
       if (splits == 9) return "mfma_f32_128x128x32_w4x2_streamk_fixup";      // single ranges + fix-up kernel (cross-check, its own bits)
       if (splits == 11) return "mfma_f32_128x128x32_w4x2_streamk_two_kernels";   // teams + fix-up kernel (cross-check); the bits of `streamk`
+      if (splits == 12) return "mfma_f32_128x128x32_w4x2_streamk_ticket";        // teams, one counter ticket per part, the last ticket gathers; the bits of `streamk`
       return splits > 1 ? split_names[splits] : mm::mfma_f32_name(v);
     }
     case FAM_MFMA_F64: return mm::mfma_f64_name(p);

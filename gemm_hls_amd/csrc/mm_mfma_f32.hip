@@ -44,8 +44,9 @@
 // What this file holds is what MM_PATH_AUTO can dispatch plus two independently scheduled cross-check
 // geometries: the three big-tile geometries through one kernel body (tile_body), and around it the launch forms for
 // problems that do not fill whole rounds of tiles -- the 64 x 64 geometry (below a round of 128 x 128 tiles; its own small
-// kernel, same per-element arithmetic), split-K with an ordered reduce kernel (few tiles, long K), stream-K in teams with
-// a fix-up kernel (between whole rounds; the in-launch hand-over form is opt-in), and a transposition pre-pass for a K x N A outside whole rounds
+// kernel, same per-element arithmetic), split-K with an ordered reduce kernel (few tiles, long K), stream-K in teams, ONE
+// kernel in which the last part of a cut tile to arrive gathers (between whole rounds; Combine::LastArriver -- the two-kernel
+// fix-up form and the counter-ticket form are the cross-checks, f32_splitk 11 / 12), and a transposition pre-pass for a K x N A outside whole rounds
 // of the K x N kernel.  Every one of them is deterministic; the whole-tile forms are bit-identical to one another.
 // The schedules, ring depths and ablations this kernel went through (HISTORY.md 3.1) live in
 // tools/lab/lab_mfma_f32.hip and are built into tools/lab/libmm_gemm_amd_lab.so, not into the product.
@@ -869,7 +870,16 @@ __global__ __launch_bounds__(G::THREADS, G::MIN_WAVES) void mfma_f32_streamk_ker
 // needed every workgroup of the launch -- and of every other launch of its kind, in any process -- to be resident at once,
 // which a library cannot guarantee; the last-arriver form is as fast without waiting, so the waiting form is retired:
 // HISTORY.md, round 5.)
-enum class Combine { FixupKernel, LastArriver };
+//
+// Combine::Ticket (f32_splitk 12; round 6): the last-arriver idea written in the LANGUAGE's memory model instead of
+// this target's -- the canonical last-block pattern.  Every part stores its slot with plain stores, every thread issues an
+// agent-scope release fence, the workgroup meets at a barrier, and one thread takes a TICKET with a single agent-scope acq_rel
+// read-modify-write on a COUNTER of the tile (not on data): the part that draws ticket parts - 1 knows -- by release / acquire
+// through the counter's modification order -- that every other part's slot is visible to it, and gathers in ascending k.  Exactly
+// one gatherer, no flag loads, no inline-asm stores, no s_waitcnt contract; the same additions in the same order, hence the same
+// bits.  The counter word carries the launch's epoch in its upper 56 bits (a compare-exchange loop, lock-free: a failed exchange
+// means another part got its ticket), so nothing is cleared between launches here either.
+enum class Combine { FixupKernel, LastArriver, Ticket };
 
 template <typename G, Combine MODE>
 __global__ __launch_bounds__(G::THREADS, G::MIN_WAVES) void mfma_f32_streamk_teams_kernel(
@@ -894,6 +904,47 @@ __global__ __launch_bounds__(G::THREADS, G::MIN_WAVES) void mfma_f32_streamk_tea
     const float *a = A + kbeg, *b = B + (size_t)kbeg * M;
     if (s0 == 0 && s1 == spt) {
       tile_body<G, false>(a, b, C, N, klen, M, K, M, N, M, row0, col0);
+    } else if constexpr (MODE == Combine::Ticket) {
+      const unsigned u_lo = st * spt, u_hi = u_lo + spt;
+      unsigned t0 = team;
+      while (t0 > 0 && sk_range_begin(units, t0, teams) > u_lo) --t0;
+      unsigned t_end = team + 1;
+      while (t_end < teams && sk_range_begin(units, t_end, teams) < u_hi) ++t_end;
+      auto part_index = [&](unsigned o) { return 2u * (o * lanes + lane) + (o == t0 ? 1u : 0u); };
+      float *slot = slots + (size_t)part_index(team) * (G::BM * G::BN);
+      float *base = (float *)((unsigned long long)slot - ((unsigned long long)row0 * G::BN + col0) * sizeof(float));
+      tile_body<G, false>(a, b, base, N, klen, M, K, G::BN, ~0u, ~0u, row0, col0);   // plain stores
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // every thread: its slot stores are ordered before whatever follows the barrier
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        // the tile's counter = the flag word of its lowest-k part (one cut tile per workgroup ends there): (epoch tag << 8) | parts arrived
+        unsigned long long *counter = flags + part_index(t0);
+        const unsigned long long tag = (epoch << 8);
+        unsigned long long seen = __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), want;
+        do {
+          want = ((seen ^ tag) >> 8) == 0 ? seen + 1 : (tag | 1ull);
+        } while (!__hip_atomic_compare_exchange_strong(counter, &seen, want, __ATOMIC_ACQ_REL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        gather_here = (unsigned)(want & 0xffu) == t_end - t0;   // the last ticket of the tile
+      }
+      __syncthreads();
+      if (gather_here) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        constexpr int QUADS = G::BM * G::BN / 4 / G::THREADS;
+        f32x4 acc[QUADS];
+        const f32x4 *first = (const f32x4 *)(slots + (size_t)part_index(t0) * (G::BM * G::BN));
+#pragma unroll
+        for (int i = 0; i < QUADS; ++i) acc[i] = first[i * G::THREADS + threadIdx.x];
+        for (unsigned o = t0 + 1; o < t_end; ++o) {
+          const f32x4 *src = (const f32x4 *)(slots + (size_t)part_index(o) * (G::BM * G::BN));
+#pragma unroll
+          for (int i = 0; i < QUADS; ++i) acc[i] += src[i * G::THREADS + threadIdx.x];
+        }
+#pragma unroll
+        for (int i = 0; i < QUADS; ++i) {
+          const unsigned q = i * G::THREADS + threadIdx.x, row = row0 + q / (G::BN / 4), col = col0 + (q % (G::BN / 4)) * 4;
+          if (row < N && col < M) *(f32x4 *)(C + (size_t)row * M + col) = acc[i];
+        }
+      }
     } else if constexpr (MODE == Combine::LastArriver) {
       // a part of a cut tile.  The tile's parts belong to teams t0 (lowest k: that team's LAST segment, slot / flag 2w' + 1)
       // and t0 + 1 .. t_end - 1 (their FIRST segments, slot / flag 2w'), same lane.
@@ -1051,13 +1102,13 @@ int launch_streamk_teams(hipStream_t s, const Problem &p) {
 // Stream-K as MM_PATH_AUTO runs it (f32_splitk 0): teams, two slots and two flags per workgroup, the last part to arrive
 // gathers -- one kernel, no workgroup waits for another one (Combine::LastArriver above).  Flags hold the launch's epoch
 // (flags_alloc, mm_capi.hip), so nothing is cleared between launches.
-template <typename G>
+template <typename G, Combine MODE = Combine::LastArriver>
 int launch_streamk_arrive(hipStream_t s, const Problem &p) {
   const TeamPlan t = streamk_team_plan<G>(p);
   const unsigned nwg = 512;
   static_assert(G::MIN_WAVES == 2, "two workgroups per CU: 64 places per XCD");
   static unsigned long long configured = 0;
-  if (int e = ensure_dynamic_lds((const void *)mfma_f32_streamk_teams_kernel<G, Combine::LastArriver>, G::LDS_BYTES, configured)) return e;
+  if (int e = ensure_dynamic_lds((const void *)mfma_f32_streamk_teams_kernel<G, MODE>, G::LDS_BYTES, configured)) return e;
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return (int)e;
@@ -1073,7 +1124,7 @@ int launch_streamk_arrive(hipStream_t s, const Problem &p) {
   if (rc == 0) rc = flags_alloc(dev, s, (size_t)2 * nwg * sizeof(unsigned long long), &flags, &epoch);
   if (rc == 0) {
     (void)hipGetLastError();
-    hipLaunchKernelGGL((mfma_f32_streamk_teams_kernel<G, Combine::LastArriver>), dim3(nwg), dim3(G::THREADS), G::LDS_BYTES, s,
+    hipLaunchKernelGGL((mfma_f32_streamk_teams_kernel<G, MODE>), dim3(nwg), dim3(G::THREADS), G::LDS_BYTES, s,
                        (const float *)p.a, (const float *)p.b, (float *)p.c, p.n, p.k, p.m, t.tiles_n, t.tiles_m, t.spt, t.sr, t.sc,
                        t.teams_per_xcd, t.teams, slots, (unsigned long long *)flags, epoch);
     rc = (int)hipGetLastError();
@@ -1448,7 +1499,7 @@ int mfma_f32_splitk(const Problem &p, int variant) {
   if (variant != 35) return 1;
   const int knob = tuning(TUNE_F32_SPLITK);
   const unsigned long long sk_units = (unsigned long long)((p.n + 127) / 128) * ((p.m + 127) / 128) * (p.k / 32);   // the kernels count units in 32 bits
-  if (knob == 0 || knob == 9 || knob == 11) return (p.k % 32 == 0 && p.k >= 64 && sk_units < (1ull << 31)) ? knob : 1;   // stream-K forced: 0 = teams, last arriver gathers (the one auto takes), 11 = teams + fix-up kernel, 9 = single ranges + fix-up kernel
+  if (knob == 0 || knob == 9 || knob == 11 || knob == 12) return (p.k % 32 == 0 && p.k >= 64 && sk_units < (1ull << 31)) ? knob : 1;   // stream-K forced: 0 = teams, last arriver gathers (the one auto takes), 11 = teams + fix-up kernel, 9 = single ranges + fix-up kernel
   const unsigned rows = p.n_total ? p.n_total : p.n;   // of the whole job (Problem::n_total)
   const unsigned long long tiles = (unsigned long long)((rows + 127) / 128) * ((p.m + 127) / 128);
   unsigned s;
@@ -1509,6 +1560,7 @@ int launch_mfma_f32(hipStream_t s, const Problem &p, int variant) {
       const int splits = mfma_f32_splitk(p, v);
       if (splits == 0) return sdma_fits(p, 32) ? launch_streamk_arrive<T128x128>(s, p) : launch_streamk_arrive<T128x128v>(s, p);
       if (splits == 11) return sdma_fits(p, 32) ? launch_streamk_teams<T128x128>(s, p) : launch_streamk_teams<T128x128v>(s, p);
+      if (splits == 12) return sdma_fits(p, 32) ? launch_streamk_arrive<T128x128, Combine::Ticket>(s, p) : launch_streamk_arrive<T128x128v, Combine::Ticket>(s, p);
       if (splits == 9) return sdma_fits(p, 32) ? launch_streamk<T128x128>(s, p) : launch_streamk<T128x128v>(s, p);
       return sdma_fits(p, 32) ? launch_geo<T128x128>(s, p, (unsigned)splits) : launch_geo<T128x128v>(s, p, (unsigned)splits);
     }

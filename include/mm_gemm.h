@@ -247,7 +247,10 @@ int mm_kernel_info(const mm_config_t *cfg, unsigned size_n, unsigned size_k, uns
  * slot and raises a flag, and the LAST part to arrive adds the slots in ascending k into C -- one kernel in which no workgroup
  * ever waits for another one, so it is sound next to anything else on the device (other streams, other processes), on
  * CU-masked streams, on partitions and in graphs; 11 the same with a small fix-up kernel doing the gather (cross-check, the
- * bits of 0); 9 stream-K in single ranges with its own fix-up kernel (cross-check, its own bits).
+ * bits of 0); 12 the same again with the hand-over written as the canonical last-block pattern -- a release fence, ONE agent-scope acq_rel
+ * read-modify-write per part on a per-tile counter, the last ticket gathers: correct by the language's memory model alone, the bits of 0,
+ * 0.2-30 % slower (its release fence writes the L2 back; profiles/r06d_*), kept as the cross-check of the shipped flag protocol; 9 stream-K in
+ * single ranges with its own fix-up kernel (cross-check, its own bits).
  * "debug_poison" = 1 fills the scratch that kernels hand partial tiles through, and C itself (pure output), with NaN before
  * every stream-K launch: a read of anything the launch did not write, or a tile nobody finished, then shows in C (tests only).  "md_virtual_devices": see mm_gemm_multi_device.  Any
  * other id is refused: the retired schedules and the work-skipping ablations of the measurement history exist only in the

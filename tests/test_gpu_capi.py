@@ -405,7 +405,7 @@ def test_enqueue_is_capturable_into_a_hip_graph(path_name, shape):
     graph capture, which puts its capture stream in hipStreamCaptureModeGlobal)."""
     import torch
     path = g.PATH_SPLIT if path_name == "split" else g.PATH_AUTO
-    n, k, m = shape     # whole tiles (64 x 64 geometry twice) / split-K (8 chunks + the ordered reduction) / stream-K (teams kernel + fix-up kernel) under AUTO
+    n, k, m = shape     # whole tiles (64 x 64 geometry twice) / split-K (8 chunks + the ordered reduction) / stream-K (ONE teams kernel, the last part to arrive gathers: Combine::LastArriver) under AUTO
     if path_name == "split" and shape != (384, 256, 320):
         pytest.skip("one shape is enough for the opt-in path")
     a, b = _oracle.fill("float", n, k, m)
@@ -414,7 +414,13 @@ def test_enqueue_is_capturable_into_a_hip_graph(path_name, shape):
         expect = {(384, 256, 320): "64x64x32", (512, 1024, 512): "64x64x32", (384, 4096, 256): "splitk8", (2304, 256, 2304): "streamk"}[shape]
         assert expect in g.kernel_name(g.make_config("float"), n, k, m)
     outs = [torch.zeros((n, m), dtype=torch.float32, device="cuda") for _ in range(4)]
-    # (stream-K under MM_PATH_AUTO is the two-kernel form, eager and captured alike: a replay gives the eager call's bits)
+    # Stream-K under MM_PATH_AUTO is the one-kernel last-arriver form with epoch flags, eager and captured alike.  A captured
+    # launch has its epoch BAKED INTO the graph, so every replay raises the same value: replay correctness rests on
+    # flags_alloc() (mm_capi.hip) adding a memset node for the flag block whenever the stream is capturing -- the flags are
+    # cleared on EVERY replay, in stream order before the kernel -- instead of relying on "never held this epoch before" as
+    # eager launches do.  The four captured launches below share one graph and three replays: if that memset node were
+    # missing, the second replay would find all flags already raised, the first part to arrive would gather slots the other
+    # parts have not written yet, and `o` would differ from `want`.
     want = g.matmul(ta, tb, path=path).clone()      # also warms up: function attributes, pool configuration
     torch.cuda.synchronize()
     graph = torch.cuda.CUDAGraph()

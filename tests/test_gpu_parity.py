@@ -227,8 +227,11 @@ def test_f32_stream_k_for_partial_rounds_is_deterministic_and_accurate(shape, fo
     (tile, slab) units -- to teams of up to 4 x 4 workgroups on neighbouring tiles, so that an XCD's L2 still shares the
     slabs.  A tile cut by a range boundary is finished in ascending k from scratch slots, in two interchangeable ways:
     the LAST PART TO ARRIVE gathers (what MM_PATH_AUTO runs, f32_splitk 0: one kernel, every part raises a flag and then
-    looks at the others' -- nobody waits), or a small second kernel gathers (11, the cross-check).  Both perform the same
-    additions in the same order: BIT-IDENTICAL.  (Rounds 3-4's form, in which the owner of the lowest-k part waited for the
+    looks at the others' -- nobody waits), or a small second kernel gathers (11, the cross-check), or every part draws a
+    TICKET from a per-tile counter with one agent-scope acq_rel read-modify-write after a release fence and the last ticket
+    gathers (12: the canonical last-block pattern, correct by the language's memory model alone; 0.2-30 % slower than the
+    shipped form -- its release fence writes the L2 back -- profiles/r06d_*).  All perform the same additions in the same
+    order: BIT-IDENTICAL.  (Rounds 3-4's form, in which the owner of the lowest-k part waited for the
     others inside the launch, is retired: it gave these bits too, was no faster, and could not be made safe next to other
     processes.)  Same bits on every launch; inside the fp32 bound; picked by the shape-adaptive rule where it pays (`auto` cases) and
     forcible (ragged N / M, K of 3 slabs, ranges shorter than a tile, one tile cut 512 ways).  f32_splitk = 9 is the
@@ -250,6 +253,9 @@ def test_f32_stream_k_for_partial_rounds_is_deterministic_and_accurate(shape, fo
         g.set_tuning("f32_splitk", 11)
         name_two = g.kernel_name(g.make_config("float"), n, k, m)
         c_two = [g.matmul_capi(a, b)[0] for _ in range(2)]
+        g.set_tuning("f32_splitk", 12)      # the counter-ticket form: the last-arriver idea in the language's memory model
+        name_ticket = g.kernel_name(g.make_config("float"), n, k, m)
+        c_ticket = [g.matmul_capi(a, b)[0] for _ in range(2)]
         g.set_tuning("f32_splitk", 9)
         name_fixup = g.kernel_name(g.make_config("float"), n, k, m)
         c_fixup, _ = g.matmul_capi(a, b)
@@ -264,6 +270,8 @@ def test_f32_stream_k_for_partial_rounds_is_deterministic_and_accurate(shape, fo
     assert np.array_equal(c1, runs[1]) and np.array_equal(c1, runs[2])
     assert name_two == "mfma_f32_128x128x32_w4x2_streamk_two_kernels", name_two
     assert np.array_equal(c1, c_two[0]) and np.array_equal(c1, c_two[1]), "last-arriver form != two-kernel form"
+    assert name_ticket == "mfma_f32_128x128x32_w4x2_streamk_ticket", name_ticket
+    assert np.array_equal(c1, c_ticket[0]) and np.array_equal(c1, c_ticket[1]), "last-arriver form != counter-ticket form"
     # the bar first (BASELINE.json north_star, applied normwise on this mixed-sign data) ...
     for what, c in (("teams + fix-up", c1), ("single ranges + fix-up", c_fixup), ("unsplit", c_one)):
         _bounds.north_star(_bounds.normwise(c, exact, scale), f"{what} {n}x{k}x{m}")
