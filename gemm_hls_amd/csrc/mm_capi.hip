@@ -247,7 +247,7 @@ int mm::workspace_pool(int dev, hipMemPool_t *out) {
   return 0;
 }
 
-// Flags of the stream-K launches (mm_mfma_f32.hip: launch_streamk_arrive).  A flag is "raised" when it holds the
+// Flags of the stream-K launches (mm_mfma_f32_streamk.inc: launch_streamk_arrive).  A flag is "raised" when it holds the
 // launch's EPOCH, a process-wide 64-bit count that no two launches share, so flags never have to be lowered -- provided the
 // memory they live in has never held anything but zeros and epochs.  Hence a second pool of this library's own that
 // serves nothing else, every block of it cleared (stream-ordered) the first time its address is handed out.  That saves

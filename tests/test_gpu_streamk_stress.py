@@ -1,4 +1,4 @@
-"""Stress of stream-K's partial-tile traffic (gemm_hls_amd/csrc/mm_mfma_f32.hip: mfma_f32_streamk_teams_kernel) in both of its
+"""Stress of stream-K's partial-tile traffic (gemm_hls_amd/csrc/mm_mfma_f32_streamk.inc, a part of mm_mfma_f32.hip: mfma_f32_streamk_teams_kernel) in both of its
 forms -- `default` (what MM_PATH_AUTO runs since round 5: every part of a cut tile goes to a scratch slot and raises an epoch
 flag, the LAST part to arrive gathers; nobody waits inside the kernel) and `two_kernel` (f32_splitk 11: a fix-up kernel
 gathers).  What a clean run cannot see:

@@ -1,4 +1,4 @@
-"""The machine code of the stream-K kernel (gemm_hls_amd/csrc/mm_mfma_f32.hip: mfma_f32_streamk_teams_kernel), checked on the gfx950
+"""The machine code of the stream-K kernel (gemm_hls_amd/csrc/mm_mfma_f32_streamk.inc, a part of mm_mfma_f32.hip: mfma_f32_streamk_teams_kernel), checked on the gfx950
 ISA hipcc emits for the shipped source with the build's flags.
 
 In the form MM_PATH_AUTO runs (Combine::LastArriver) the parts of a tile that a range boundary cuts go to scratch slots, each
@@ -59,14 +59,14 @@ def ordered_kernels():
             kernels[name] = body
             name = None
     picked = {k: v for k, v in kernels.items() if "mfma_f32_streamk_teams_kernel" in k}
-    assert len(picked) == 4, list(kernels)           # (scalar-base DMA, vector-address) x Combine::{FixupKernel, LastArriver}
+    assert len(picked) == 6, list(kernels)           # (scalar-base DMA, vector-address) x Combine::{FixupKernel, LastArriver, Ticket}
     _ALL["kernels"] = kernels
     _ALL["metadata"] = r.stdout
     return _by_combine(1)
 
 
 def _by_combine(value):
-    """The two instantiations (DMA forms) of mfma_f32_streamk_teams_kernel<G, Combine(value)>: 0 FixupKernel, 1 LastArriver."""
+    """The two instantiations (DMA forms) of mfma_f32_streamk_teams_kernel<G, Combine(value)>: 0 FixupKernel, 1 LastArriver, 2 Ticket."""
     picked = {k: v for k, v in _ALL["kernels"].items() if "mfma_f32_streamk_teams_kernel" in k and f"CombineE{value}EEEv" in k}
     assert len(picked) == 2, [k for k in _ALL["kernels"] if "streamk_teams" in k]
     return picked
@@ -102,6 +102,19 @@ def test_the_two_kernel_cross_check_form_has_no_inter_workgroup_communication(or
         assert not any("atomic" in t for t in body), name
     fix = [k for k in _ALL["kernels"] if "streamk_teams_fixup_kernel" in k]
     assert len(fix) == 1 and not any("atomic" in t or _is("s_sleep", t) for t in _ALL["kernels"][fix[0]])
+
+
+def test_the_counter_ticket_cross_check_form_is_what_the_language_model_compiles_to(ordered_kernels):
+    """mfma_f32_streamk_teams_kernel<G, Combine::Ticket> (f32_splitk 12, round 6): the canonical last-block pattern -- plain slot
+    stores, an agent-scope RELEASE fence in every thread (on this target: the L2 write-back the shipped form avoids, which is what
+    it costs), ONE compare-exchange per part on the tile's counter, an agent-scope ACQUIRE (invalidate) before the gather; no
+    hand-placed sc1 stores, no flag loads, no sleep.  Pinned so that the cross-check stays the independent implementation it is."""
+    for name, body in _by_combine(2).items():
+        assert any(_is("buffer_wbl2", t) for t in body), name                                   # the release fence
+        assert sum(1 for t in body if t.startswith("global_atomic_cmpswap")) >= 1, name          # the ticket
+        assert any(t.startswith("buffer_inv") for t in body), name                              # the acquire
+        assert not any(t.startswith("global_store_dwordx4") and t.endswith("sc1") for t in body), name
+        assert not any(_is("s_sleep", t) for t in body), name
 
 
 def test_no_shipped_matrix_core_kernel_of_this_unit_spills(ordered_kernels):

@@ -456,7 +456,7 @@ def test_pingpong_16x16_kxn_a_gather_f16_and_i8():
 
 
 # ---------------------------------------------------------------- fp32 64 x 64 geometry (round 3) ------------
-# gemm_hls_amd/csrc/mm_mfma_f32.hip: mfma_f32_small_kernel.  A slab [64 rows][8 chunks of 4 k], chunk ^ (row >> 1) & 7;
+# gemm_hls_amd/csrc/mm_mfma_f32_small.inc: mfma_f32_small_kernel.  A slab [64 rows][8 chunks of 4 k], chunk ^ (row >> 1) & 7;
 # B slab [32 k][16 chunks of 4 columns], chunk ^ 8 for k & 4, read one float per lane (ds_read_b32 / ds_read2st64_b32).
 def test_f32_small_a_image_roundtrip_and_banks():
     lds = {}

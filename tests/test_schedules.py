@@ -244,7 +244,7 @@ def test_the_model_catches_a_wrong_count():
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-# Stream-K unit ranges (gemm_hls_amd/csrc/mm_mfma_f32.hip: mfma_f32_streamk_kernel / streamk_fixup_kernel), replayed on
+# Stream-K unit ranges (gemm_hls_amd/csrc/mm_mfma_f32_streamk.inc: mfma_f32_streamk_kernel / streamk_fixup_kernel), replayed on
 # the CPU with the kernels' own integer formulas: every (tile, slab) unit is multiplied exactly once, a workgroup writes at
 # most one head and one tail slot, and the fix-up of a tile adds exactly the slots that were written for it, in ascending k.
 def _sk_begin(units, w, nwg):
