@@ -254,3 +254,44 @@ def test_multi_device_bench_control_plane_on_rccl_with_one_rank():
         # bench.py falls back to gloo for barrier / max when RCCL cannot form (by design: the data path has no collective)
         pytest.skip("RCCL control plane did not form on this box; bench.py fell back to " + out["control_plane"]["backend"] + ": "
                     + r.stderr[-400:])
+
+
+def test_multi_device_c5a_real_size_eight_virtual_devices_sampled_rows():
+    """BASELINE configs[4] at its REAL size -- float 65536 x 16384 x 16384 split along N over G = 8 -- through
+    mm_gemm_multi_device itself (the one configuration of the split that had only ever run through
+    bench.py): eight logical devices dealt out over the box's GPU(s), 8192-row slabs on the 256 x 256 kernel, B fanned out
+    device 0 -> g, per-device kernel times from HIP events.  Checked on sampled rows of every slab (first, last, the rows either
+    side of each slab boundary) against fp64, and -- whole output, 4 GiB -- bit for bit against the one-device launch."""
+    import torch
+    n, k, m, G = 65536, 16384, 16384, 8
+    rng = np.random.default_rng(65)
+    b = rng.uniform(1, 10, size=(k, m)).astype(np.float32)
+    a = np.empty((n, k), np.float32)
+    for r0 in range(0, n, 8192):                      # filled slab by slab: no 8-GiB fp64 temporary
+        a[r0:r0 + 8192] = rng.uniform(1, 10, size=(8192, k)).astype(np.float32)
+    g.set_tuning("md_virtual_devices", G)
+    try:
+        cfg = g.make_config("float")
+        assert [g.row_slab(cfg, n, k, m, G, r) for r in range(G)] == [(8192 * r, 8192) for r in range(G)]
+        assert g.kernel_name(cfg, 8192, k, m) == "mfma_f32_256x256x16_w8_flush4096"
+        c8, t, per_device, wall = g.matmul_host(a, b, devices=G, timing=True)
+    finally:
+        g.set_tuning("md_virtual_devices", -1)
+    assert len(per_device) == G and all(x > 0 for x in per_device) and t == max(per_device) and wall >= t
+    rows = sorted({0, 1, n - 1} | {r for s in range(1, G) for r in (8192 * s - 1, 8192 * s)} | set(rng.integers(0, n, 8).tolist()))
+    b64 = b.astype(np.float64)
+    exact = a[rows].astype(np.float64) @ b64
+    assert np.max(np.abs(c8[rows] - exact) / exact) < 1e-5
+    del b64, exact
+    c1, _ = g.matmul_host(a, b, devices=1)             # the same job on ONE device: the split gives its bits
+    assert np.array_equal(c8, c1)
+    # on one physical GPU the eight slabs time-share it: the job cannot beat one device's roof, and each device's own kernel
+    # time is at least a slab's worth at that roof
+    flops = 2.0 * n * k * m
+    assert flops / wall / 1e12 < 157.3 * 1.02 * max(1, torch.cuda.device_count())
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out_dir):
+        with open(os.path.join(out_dir, "multi_device_c5a_real_size_8_virtual_devices.txt"), "w") as f:
+            f.write(f"float {n}x{k}x{m} over {G} logical devices on {torch.cuda.device_count()} physical: max per-device kernel time {t:.4f} s, "
+                    f"host clock {wall:.4f} s, per device {[round(x, 4) for x in per_device]}, {flops / wall / 1e12:.1f} TF by the host clock; "
+                    f"sampled rows {rows} within 1e-5 of fp64; whole output bit-identical to the one-device launch\n")
