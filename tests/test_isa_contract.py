@@ -156,3 +156,26 @@ def test_the_last_arriver_form_is_wait_free_and_orders_raise_before_look(ordered
         assert first_barrier < first_gather, (name, first_barrier, first_gather)
         assert not any(_is("s_sleep", t) for t in body), name                      # nobody waits
         assert not any("atomic" in t for t in body) and not any(_is("buffer_wbl2", t) for t in body), name
+
+
+# ---- the k-ordered tile kernels (gemm_hls_amd/csrc/mm_valu_tile_fp_exact.hip) ------------------------------------------------------
+def test_the_k_ordered_tile_unit_has_no_fused_multiply_add_with_or_without_the_compile_flag():
+    """`ordered_tile` must multiply and add as two separately rounded instructions in Data_t -- the reference's arithmetic
+    (kernel/Compute.cpp:129-133; binary16 accumulating in binary16) -- or its bits are not Naive's.  The unit says so twice: the
+    build passes -ffp-contract=off AND the file carries `#pragma clang fp contract(off)`; this compiles it WITHOUT the flag and
+    looks at the machine code of all of its kernels: no fused multiply-add of any floating type, packed or not, no dot
+    product; and the packed binary16 pair the half kernels are priced against is what the inner loop is made of."""
+    from gemm_hls_amd import build
+    src = os.path.join(ROOT, "gemm_hls_amd", "csrc", "mm_valu_tile_fp_exact.hip")
+    assert build.EXTRA.get("mm_valu_tile_fp_exact.hip") == ["-ffp-contract=off"] and build.EXTRA.get("mm_ordered.hip") == ["-ffp-contract=off"]
+    flags = [f for f in build.COMMON if f != "--offload-compress"]           # NOT the per-file extra flag: the pragma alone must do
+    r = subprocess.run([HIPCC, *flags, "-S", "--cuda-device-only", src, "-o", "-"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    ops = [ln.split()[0] for ln in r.stdout.split("\n") if ln.startswith("\tv_")]
+    fused = sorted({op for op in ops if re.match(r"v_(pk_)?(fma|fmac|mad|mac|dot\d*c?)_", op) and not re.search(r"_(u|i)(8|16|24|32|64)", op)})
+    assert fused == [], fused
+    assert ops.count("v_pk_mul_f16") >= 128 and ops.count("v_pk_add_f16") >= 128           # half: two elements per lane and instruction
+    assert ops.count("v_mul_f64_e32") + ops.count("v_mul_f64") >= 64 and ops.count("v_add_f64_e32") + ops.count("v_add_f64") >= 64
+    # std::min / std::max to the letter: compare-and-select, not the hardware minNum / maxNum of the fast family
+    assert not any(op.startswith(("v_min_f", "v_max_f", "v_min3_f", "v_max3_f", "v_pk_min_f", "v_pk_max_f")) for op in ops), \
+        sorted({op for op in ops if op.startswith(("v_min", "v_max", "v_pk_min", "v_pk_max"))})
