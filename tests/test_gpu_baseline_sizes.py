@@ -284,6 +284,38 @@ def test_c1_float_1024_device_next_to_the_reference_kernel_itself():
     assert _oracle.compare("float", c_ref, _oracle.naive("float", "Multiply", "Add", a, b), 1e-3)[0] == 0
 
 
+def test_half_reference_contract_next_to_the_reference_kernel_itself():
+    """The reference's kernel for MM_DATA_TYPE=half (its kernel/*.cpp compiled against the test-only shim into oracle/_ref), run LIVE
+    on its seeded 512 x 1024 x 544 inputs -- K = 1024 on [1,10): running sums reach ~31 000, where one binary16 ulp is 16, so
+    every one of the 1024 roundings of each output matters -- and the device beside it: MM_PATH_AUTO under half_contract =
+    reference and MM_PATH_ORDERED must both give the reference kernel's bits (kernel/Compute.cpp:129-133), from the tile kernel
+    and from the anchor; the default contract (f32 accumulation, one rounding) is the more accurate one and so differs."""
+    if not _oracle.ref_available("half", "Multiply", "Add"):
+        pytest.skip("oracle/_ref (half build) not in this snapshot (needs /root/reference at build time)")
+    n, k, m = 512, 1024, 544
+    a, b = _oracle.fill("half", n, k, m)
+    c_ref = _oracle.ref_kernel("half", "Multiply", "Add", a, b)
+    assert np.isfinite(c_ref.astype(np.float32)).all()
+    bits = lambda x: x.view(np.uint16)   # noqa: E731
+    try:
+        g.set_tuning("half_contract", 1)
+        assert g.kernel_name(g.make_config("half"), n, k, m) == "ordered_tile"
+        c_auto, _ = g.matmul_capi(a, b, "half")
+        g.set_tuning("half_contract", -1)
+        c_ord, _ = g.matmul_capi(a, b, "half", path=g.PATH_ORDERED)
+        g.set_tuning("ordered_variant", 0)
+        c_anchor, _ = g.matmul_capi(a, b, "half", path=g.PATH_ORDERED)
+    finally:
+        g.set_tuning("half_contract", -1)
+        g.set_tuning("ordered_variant", -1)
+    assert np.array_equal(bits(c_auto), bits(c_ref)) and np.array_equal(bits(c_ord), bits(c_ref)) and np.array_equal(bits(c_anchor), bits(c_ref))
+    c_wide, _ = g.matmul_capi(a, b, "half")
+    exact = a.astype(np.float64) @ b.astype(np.float64)
+    err_ref = np.abs(c_ref.astype(np.float64) - exact) / exact
+    err_wide = np.abs(c_wide.astype(np.float64) - exact) / exact
+    assert err_wide.max() <= 2.0 ** -11 < err_ref.max()        # one rounding vs 1024 of them: which is why the default is not the reference's bits
+
+
 def test_f32_rows_of_c_longer_than_the_32_bit_reach_of_the_interior_write_back():
     """the straight-line interior write-back of the shipped fp32 geometries addresses C with 32-bit
     byte offsets from a wavefront's first row (up to 64 rows x M x 4 B).  With M = 17 Mi floats that passes 4 GiB; the

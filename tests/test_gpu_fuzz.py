@@ -114,3 +114,32 @@ def test_fuzz_split_path_any_shape_mixed_sign():
         if i % 4 == 0:
             ct, _ = g.matmul_capi(np.ascontiguousarray(a.T), b, path=g.PATH_SPLIT, transposed_a=True)
             assert np.array_equal(ct, out[0]), (n, k, m)
+
+
+@pytest.mark.parametrize("dtype", ["half", "float", "double"])
+def test_fuzz_k_ordered_tile_kernel_is_naive_bit_for_bit(dtype):
+    """MM_PATH_ORDERED (Multiply, Add) on the floating types -- the unfused, k-ascending contract of the reference's kernel
+    (kernel/Compute.cpp:129-133), binary16 accumulating in binary16 for half -- through the register-tile kernel
+    (mm_valu_tile_fp_exact.hip), on shapes with ragged N, one-chunk M, K below / not a multiple of the slab depth (synchronous
+    staging, the shifted last slab) and K x N A: the bits of the CPU oracle's Naive and of the 64 x 64 anchor kernel."""
+    rng = np.random.default_rng(zlib.crc32(("ordered" + dtype).encode()))
+    for i, (n, k, m) in enumerate(_shapes(rng, 4, 4, 30 * SCALE)):
+        k = min(k, 700)
+        ta = i % 3 == 2
+        if ta:
+            n = (n + 3) // 4 * 4                              # a K x N A is served by the tile kernel when N % 4 == 0
+        a, b = _oracle.fill(dtype, n, k, m)
+        if dtype == "half":                                   # keep most binary16 sums finite so that the bits say something
+            a, b = (a * np.float16(0.125)).astype(np.float16), (b * np.float16(0.25)).astype(np.float16)
+        want = _oracle.naive(dtype, "Multiply", "Add", a, b)
+        a_dev = np.ascontiguousarray(a.T) if ta else a
+        assert g.kernel_name(g.make_config(dtype, path=g.PATH_ORDERED, transposed_a=ta), n, k, m) == "ordered_tile"
+        c_tile, _ = g.matmul_capi(a_dev, b, dtype, path=g.PATH_ORDERED, transposed_a=ta)
+        assert np.array_equal(c_tile.view(np.uint8), want.view(np.uint8)), (dtype, n, k, m, ta)
+        if i % 5 == 0:
+            g.set_tuning("ordered_variant", 0)
+            try:
+                c_anchor, _ = g.matmul_capi(a_dev, b, dtype, path=g.PATH_ORDERED, transposed_a=ta)
+            finally:
+                g.set_tuning("ordered_variant", -1)
+            assert np.array_equal(c_anchor.view(np.uint8), want.view(np.uint8)), (dtype, n, k, m, ta)
