@@ -294,6 +294,97 @@ def live_counters(kernel_name, shape, avg_launch_ms, key="float", timeout=75):
         shutil.rmtree(workdir, ignore_errors=True)
 
 
+class HbmBusy:
+    """The DRAM-side figure ("achieved HBM GB/s").  rocprofv3 on this part counts nothing behind the Infinity Cache, but
+    the amdgpu driver exports the memory controller's activity as the SMU reports it: /sys/bus/pci/devices/<bdf>/mem_busy_percent.  It is a
+    LINEAR measure of HBM bytes per second -- a 4-GiB device copy (4.9 TB/s known) and a 4-GiB fill (6.9 TB/s known) give the same 82.0 GB/s
+    per percent, i.e. 100 % = 8.2 TB/s (profiles/r06g_hbm_busy_percent_calibrated_copy_fill_and_kernels.json) -- so sampled while a kernel
+    is launched back to back, and calibrated IN THIS RUN on the same two known streams, it says what the kernel pulls from HBM (resolution:
+    one percent = 82 GB/s).  Untimed legs after the timed regions; None wherever sysfs does not offer the file."""
+
+    def __init__(self, g, torch, dev, local_rank):
+        self.torch, self.dev, self.path, self.k, self.cal = torch, dev, None, None, None
+        if os.environ.get("MM_BENCH_NO_HBM_PROBE"):
+            return
+        try:
+            buf = ctypes.create_string_buffer(32)
+            g._check(g.lib().mm_device_pci_bus_id(local_rank, buf, 32))
+            path = f"/sys/bus/pci/devices/{buf.value.decode().lower()}/mem_busy_percent"
+            if self._read(path) is not None:
+                self.path = path
+        except Exception:
+            pass
+
+    @staticmethod
+    def _read(path):
+        try:
+            with open(path) as f:
+                return int(f.read().strip())
+        except Exception:
+            return None
+
+    def busy(self, launch, seconds=1.0, depth=4):
+        """Mean mem_busy_percent over ~`seconds` of back-to-back `launch()`es (at most `depth` in flight), the first 0.3 s discarded."""
+        import threading
+        samples, stop = [], threading.Event()
+
+        def sampler():
+            t0 = time.perf_counter()
+            while not stop.is_set():
+                v = self._read(self.path)
+                if v is not None and time.perf_counter() - t0 > 0.3:
+                    samples.append(v)
+                time.sleep(0.005)
+
+        th = threading.Thread(target=sampler)
+        th.start()
+        t0, calls = time.perf_counter(), 0
+        try:
+            while time.perf_counter() - t0 < seconds or calls < depth:
+                for _ in range(depth):
+                    launch()
+                calls += depth
+                self.torch.cuda.synchronize()
+        finally:
+            stop.set()
+            th.join()
+        wall = time.perf_counter() - t0
+        return (sum(samples) / len(samples) if samples else None), calls, wall
+
+    def calibrate(self):
+        if self.path is None or self.k is not None:
+            return
+        torch = self.torch
+        src = torch.empty(1 << 30, dtype=torch.float32, device=self.dev)      # 4 GiB: far beyond the 256-MiB Infinity Cache
+        dst = torch.empty_like(src)
+        src.fill_(1.0)
+        pc, calls, wall = self.busy(lambda: dst.copy_(src), 0.8, depth=16)
+        copy_gbps = 2.0 * src.numel() * 4 * calls / wall / 1e9
+        pf, calls, wall = self.busy(lambda: dst.fill_(2.0), 0.8, depth=16)
+        fill_gbps = 1.0 * src.numel() * 4 * calls / wall / 1e9
+        del src, dst
+        torch.cuda.empty_cache()
+        if pc and pf:
+            self.k = 0.5 * (copy_gbps / pc + fill_gbps / pf)
+            self.cal = {"copy_4GiB": {"known_GBps": round(copy_gbps, 1), "mem_busy_pct": round(pc, 2), "GBps_per_pct": round(copy_gbps / pc, 1)},
+                        "fill_4GiB": {"known_GBps": round(fill_gbps, 1), "mem_busy_pct": round(pf, 2), "GBps_per_pct": round(fill_gbps / pf, 1)}}
+
+    def attach(self, roofline, launch):
+        """Adds the DRAM-side figures of the kernel behind `launch` to a roofline object."""
+        if self.path is None:
+            return
+        try:
+            self.calibrate()
+            pct, _, _ = self.busy(launch, 1.0)
+            if pct is None or self.k is None:
+                return
+            roofline["hbm_busy_pct"] = round(pct, 2)
+            roofline["achieved_HBM_GBps"] = round(self.k * pct, 1)
+            roofline["achieved_HBM_frac_of_8TBps"] = round(self.k * pct / 8000.0, 4)
+        except Exception as exc:          # never the line's problem
+            sys.stderr.write(f"[bench] HBM busy probe failed: {exc!r}\n")
+
+
 def attach_replayed(roofline, kernel_name, shape, dtype=None):
     """Adds the replayed counters to a roofline object; `achieved_fabric_GBps` = replayed bytes per launch over the
     launch time measured live in this run."""
@@ -357,7 +448,7 @@ def roofline_obj(dtype, roof, peak, rows, k, m, launch_ms):
             "avg_launch_ms": round(1e3 * avg_s, 4)}   # (what the part sustains from registers alone: top-level "context")
 
 
-def extra_workloads(g, torch, dev, local_rank, default_steps=5):
+def extra_workloads(g, torch, dev, local_rank, default_steps=5, hbm=None):
     """The other single-GPU BASELINE configs, a few steps each, in the same process."""
     out = []
     # (MM_EXTRA_KXN=1 adds half_kxn / uint8_kxn, round 4's one-round extras: the same problems with A handed over K x N,
@@ -385,6 +476,8 @@ def extra_workloads(g, torch, dev, local_rank, default_steps=5):
                      "ms_per_step": round(1e3 * elapsed / steps, 4),
                      "roofline": roofline_obj(dtype, roof, peak, rows, k, m, launch_ms)}
             entry["key"] = key
+            if hbm is not None and key in ("half", "double", "minplus", "uint8", "half_exact") and not kxn:
+                hbm.attach(entry["roofline"], lambda: g.matmul(a, b, dtype, map_op, reduce_op, path=path, out=c))
             for drop in ("algorithmic_flops_per_launch", "algorithmic_bytes_per_launch"):   # derivable from the shape; the headline keeps them
                 entry["roofline"].pop(drop, None)
             if not kxn:   # (two kernels per step there: no single kernel's counters apply)
@@ -409,7 +502,10 @@ def baseline_summary(out):
     """BASELINE.json's configs, one compact entry each: value (GOp/s), ms per step, fraction of the roof, kernel.  Well under
     1 KB, so that it survives in the tail of the line that the driver's record keeps."""
     def brief(value, ms, rl, kernel):
-        return {"value": value, "ms": round(ms, 3), "frac": rl.get("frac"), "kernel": kernel}
+        b = {"value": value, "ms": round(ms, 3), "frac": rl.get("frac"), "kernel": kernel}
+        if rl.get("achieved_HBM_GBps") is not None:
+            b["hbm_GBps"] = rl["achieved_HBM_GBps"]       # DRAM side (sysfs mem_busy_percent, calibrated in the run): notes.hbm
+        return b
     summary = {"unit": "GOp/s", "C2_float_16384": brief(out["value"], out["ms_per_step"], out["roofline"], out["config"]["kernel"])}
     names = {"half": "C3_half_32768", "half_exact": "C3_half_32768_reference_contract", "double": "C4_double_16384", "minplus": "C5b_minplus_8192",
              "float": "C5a_float_65536_rows_1gpu"}
@@ -574,6 +670,8 @@ def main():
         return g.row_slab(job_cfg, n_total, k, m, world_size, r)
 
     headline = args.workload == "float" and args.size == SIZE
+    hbm = HbmBusy(g, torch, dev, local_rank) if (world == 1 and not args.no_extra) else None
+    hbm_box = {}
 
     def run_job(n_total, seed_base):
         """One timed region of the contract over the job of n_total rows; rank r owns row_slab(r)."""
@@ -582,6 +680,9 @@ def main():
         own_elapsed, launch_ms = timed_steps(g, torch, a, b, c, dtype, map_op, reduce_op, args.steps, args.warmup, barrier,
                                              PATHS.get(args.workload, 0))
         elapsed = max_over_ranks(own_elapsed)
+        if hbm is not None and world == 1:    # the DRAM-side figure of this kernel: an untimed leg of back-to-back launches, after the timed region
+            hbm_box.clear()
+            hbm.attach(hbm_box, lambda: g.matmul(a, b, dtype, map_op, reduce_op, path=PATHS.get(args.workload, 0), out=c))
         a = b = c = None
         torch.cuda.empty_cache()
         # what THIS rank did, in its own words: if the job lands at 6.6x instead of 8x the line says which rank, on which PCI
@@ -615,6 +716,7 @@ def main():
         flops_job = 2.0 * n_total * k * m
         value = 1e-9 * flops_job * args.steps / elapsed
         rl = roofline_obj(dtype, roof, peak, rows, k, m, launch_ms)
+        rl.update(hbm_box)
         if world == 1:
             attach_replayed(rl, g.kernel_name(g.make_config(dtype, map_op, reduce_op, PATHS.get(args.workload, 0)), rows, k, m),
                             (rows, k, m), dtype)
@@ -674,7 +776,7 @@ def main():
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * w_elapsed / args.steps, 4),
                 "roofline": roofline_obj(dtype, roof, peak, w_rows, k, m, w_launch), "per_rank": w_per_rank}
         if world == 1 and headline and not args.no_extra:
-            out["workloads"] = extra_workloads(g, torch, dev, local_rank)
+            out["workloads"] = extra_workloads(g, torch, dev, local_rank, hbm=hbm)
             # the strong-scaling job (BASELINE configs[4], float 65536 x 16384 x 16384) on ONE GPU, already timed above:
             # an N = G line's value / scale_base.value is the strong-scaling factor of that job without a second run
             for w in out["workloads"]:
@@ -711,8 +813,16 @@ def main():
                             "Infinity-Cache hits.  With false, traffic (L2 <-> fabric bytes per launch, Infinity-Cache hits included), mfma_util_pct, "
                             "profiled_clock_GHz and l2_hit_rate are REPLAYED from the committed PMC files named in *_source, which profiled the "
                             "same kernel on the same shape on an earlier box",
+                "hbm": ("achieved_HBM_GBps / hbm_busy_pct: the DRAM side.  amdgpu's sysfs mem_busy_percent (the memory controller's activity as the SMU reports it) "
+                        "sampled every 5 ms over ~1 s of back-to-back launches of the same call AFTER the timed region, times a GB/s-per-percent factor "
+                        "calibrated in this run on two streams with known HBM bytes that the 256-MiB Infinity Cache cannot serve -- a 4-GiB device copy and a "
+                        "4-GiB fill (hbm_calibration; both give ~82 GB/s per percent: the figure is linear, 100 % = 8.2 TB/s).  Resolution one percent = 82 GB/s.  "
+                        "Compare with achieved_fabric_GBps (L2 <-> fabric, Infinity-Cache hits included): the difference is what the Infinity Cache serves"
+                        if hbm is not None and hbm.cal else "no mem_busy_percent in sysfs on this box (or MM_BENCH_NO_HBM_PROBE): no DRAM-side figure"),
                 "peaks": "MI355X_MICROARCH.md dense MFMA peaks (fp32 157.3, fp16 2500, i8 5000 T/s; fp64 78.6 datasheet); min-plus: SURVEY 8(d) "
                          "VALU ceiling 78.6 T lane-ops/s (fp64: 39.3); float_split: bf16 peak / 6 MFMAs per fp32 multiply-add block"}
+            if hbm is not None and hbm.cal:
+                out["hbm_calibration"] = dict(hbm.cal, GBps_per_pct_used=round(hbm.k, 1), sysfs=hbm.path)
             out["context"] = {"what_the_part_sustains_from_registers_alone": {
                 "float": MFMA_SUSTAINED["float"], "double": MFMA_SUSTAINED["double"], "half": POWER_CEILING["half"], "uint8_t": POWER_CEILING["uint8_t"],
                 "float_split": {"register_only_bf16_mfma_on_random_operands_TOps_div_6": round(SPLIT_BF16_REGISTER_ONLY_TOPS / 6.0, 1),
