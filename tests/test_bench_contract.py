@@ -189,3 +189,35 @@ def test_live_counter_passes_share_one_budget_and_stop_at_the_first_failure(monk
     assert b.live_counters("mfma_f16_256x256_pingpong_16x16x32", (32768,) * 3, 47.0, "half") is None
     assert len(calls) == 1                              # no further passes after the first failure
     assert b.LIVE_BUDGET_S <= 180
+
+
+def test_hbm_busy_probe_samples_sysfs_while_launching(tmp_path):
+    """bench.py's DRAM-side probe (HbmBusy): the mean of amdgpu's mem_busy_percent, sampled by a thread while the launch callable is
+    called back to back, the first 0.3 s discarded; attach() turns it into achieved_HBM_GBps with the run's calibration factor and
+    leaves the roofline alone where sysfs has no such file."""
+    b = _bench()
+
+    class _Cuda:
+        @staticmethod
+        def synchronize():
+            pass
+
+    class _Torch:
+        cuda = _Cuda()
+
+    sysfs = tmp_path / "mem_busy_percent"
+    sysfs.write_text("19\n")
+    probe = object.__new__(b.HbmBusy)
+    probe.torch, probe.dev, probe.path, probe.k, probe.cal = _Torch(), None, str(sysfs), 82.0, {"copy_4GiB": {}, "fill_4GiB": {}}
+    calls = []
+    pct, n, wall = probe.busy(lambda: calls.append(1), seconds=0.5, depth=4)
+    assert pct == 19 and n == len(calls) and n % 4 == 0 and wall >= 0.5
+    rl = {}
+    probe.busy = lambda launch, seconds=1.0, depth=4: (19.0, 4, 1.0)
+    probe.attach(rl, lambda: None)
+    assert rl == {"hbm_busy_pct": 19.0, "achieved_HBM_GBps": 1558.0, "achieved_HBM_frac_of_8TBps": round(1558.0 / 8000.0, 4)}
+    probe.path = None
+    rl2 = {}
+    probe.attach(rl2, lambda: None)
+    assert rl2 == {}
+    assert b.HbmBusy._read(str(tmp_path / "absent")) is None
