@@ -15,10 +15,11 @@ python bench.py --steps 20 --warmup 5 > gpurun_out/${T}_bench.json 2> gpurun_out
 python - "$T" <<'P'
 import json, sys
 d = json.loads(open(f"gpurun_out/{sys.argv[1]}_bench.json").read().strip().splitlines()[-1])
-print("headline", d["value"], d["roofline"]["frac"], {k: d["roofline"].get(k) for k in ("traffic", "dram_destined_bytes", "mfma_util_pct", "profiled_clock_GHz", "counters_measured_in_this_run", "counter_passes_s")})
+print("headline", d["value"], d["roofline"]["frac"], {k: d["roofline"].get(k) for k in ("traffic", "achieved_fabric_GBps", "achieved_HBM_GBps", "hbm_busy_pct", "dram_destined_bytes", "mfma_util_pct", "profiled_clock_GHz", "counters_measured_in_this_run", "counter_passes_s")})
 for w in d["workloads"]:
     r = w.get("roofline", {})
-    print(w.get("key"), w.get("value"), r.get("frac"), r.get("traffic"), r.get("mfma_util_pct"), r.get("profiled_clock_GHz"), r.get("counters_measured_in_this_run"))
+    print(w.get("key"), w.get("value"), r.get("frac"), r.get("traffic"), r.get("achieved_fabric_GBps"), r.get("achieved_HBM_GBps"), r.get("mfma_util_pct"), r.get("profiled_clock_GHz"), r.get("counters_measured_in_this_run"))
+print(d.get("hbm_calibration"))
 print({k: d["cpu_baseline"].get(k) for k in ("value", "seconds", "blas_sgemm_gflops_same_sample", "blas_threads", "naive_1thread_gflops_same_sample", "cpu_model")})
 P
 export TMPDIR=/tmp
