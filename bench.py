@@ -381,6 +381,8 @@ class HbmBusy:
             roofline["hbm_busy_pct"] = round(pct, 2)
             roofline["achieved_HBM_GBps"] = round(self.k * pct, 1)
             roofline["achieved_HBM_frac_of_8TBps"] = round(self.k * pct / 8000.0, 4)
+            if roofline.get("avg_launch_ms"):      # per launch, like `traffic`: what one launch pulls from / pushes to HBM
+                roofline["hbm_bytes_per_launch"] = int(self.k * pct * 1e9 * 1e-3 * roofline["avg_launch_ms"])
         except Exception as exc:          # never the line's problem
             sys.stderr.write(f"[bench] HBM busy probe failed: {exc!r}\n")
 
