@@ -50,7 +50,8 @@ def pytest_sessionstart(session):
 # and soak after those; self-imposed regression guards (throughput floors) last of all.
 _TIERS = [
     # tier 0: section-8 rows
-    (0, ("test_against_reference_kernel_golden_outputs", "test_ordered_path_", "test_ordered_transposed_a_layout",
+    (0, ("test_against_reference_kernel_golden_outputs", "test_ordered_path_", "test_ordered_transposed_a_layout", "test_ordered_tile_",
+         "test_half_reference_contract_",
          "test_reference_entry_point_", "test_kernel_shims_export_the_reference_symbol", "test_static_kernel_shim_",
          "test_c1_float_1024_device_next_to_the_reference_kernel_itself", "test_f32_mfma_default_vs_blas_and_exact",
          "test_f64_mfma_vs_blas", "test_f16_mfma_wide_accumulate_contract", "test_i8_mfma_is_bit_exact_mod_256",
