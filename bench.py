@@ -369,13 +369,13 @@ class HbmBusy:
             self.cal = {"copy_4GiB": {"known_GBps": round(copy_gbps, 1), "mem_busy_pct": round(pc, 2), "GBps_per_pct": round(copy_gbps / pc, 1)},
                         "fill_4GiB": {"known_GBps": round(fill_gbps, 1), "mem_busy_pct": round(pf, 2), "GBps_per_pct": round(fill_gbps / pf, 1)}}
 
-    def attach(self, roofline, launch):
-        """Adds the DRAM-side figures of the kernel behind `launch` to a roofline object."""
+    def attach(self, roofline, launch, depth=4):
+        """Adds the DRAM-side figures of the kernel behind `launch` to a roofline object (`depth` launches in flight at a time)."""
         if self.path is None:
             return
         try:
             self.calibrate()
-            pct, _, _ = self.busy(launch, 1.0)
+            pct, _, _ = self.busy(launch, 1.0, depth)
             if pct is None or self.k is None:
                 return
             roofline["hbm_busy_pct"] = round(pct, 2)
@@ -479,7 +479,8 @@ def extra_workloads(g, torch, dev, local_rank, default_steps=5, hbm=None):
                      "roofline": roofline_obj(dtype, roof, peak, rows, k, m, launch_ms)}
             entry["key"] = key
             if hbm is not None and key in ("half", "double", "minplus", "uint8", "half_exact") and not kxn:
-                hbm.attach(entry["roofline"], lambda: g.matmul(a, b, dtype, map_op, reduce_op, path=path, out=c))
+                hbm.attach(entry["roofline"], lambda: g.matmul(a, b, dtype, map_op, reduce_op, path=path, out=c),
+                           depth=1 if entry["ms_per_step"] > 250.0 else 4)      # (a ~1-s launch: two of them are sample enough)
             for drop in ("algorithmic_flops_per_launch", "algorithmic_bytes_per_launch"):   # derivable from the shape; the headline keeps them
                 entry["roofline"].pop(drop, None)
             if not kxn:   # (two kernels per step there: no single kernel's counters apply)

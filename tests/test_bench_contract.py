@@ -213,7 +213,7 @@ def test_hbm_busy_probe_samples_sysfs_while_launching(tmp_path):
     pct, n, wall = probe.busy(lambda: calls.append(1), seconds=0.5, depth=4)
     assert pct == 19 and n == len(calls) and n % 4 == 0 and wall >= 0.5
     rl = {"avg_launch_ms": 50.0}
-    probe.busy = lambda launch, seconds=1.0, depth=4: (19.0, 4, 1.0)
+    probe.busy = lambda launch, seconds=1.0, depth=4: (19.0, 4, 1.0)   # noqa: E731
     probe.attach(rl, lambda: None)
     assert rl == {"avg_launch_ms": 50.0, "hbm_busy_pct": 19.0, "achieved_HBM_GBps": 1558.0, "achieved_HBM_frac_of_8TBps": round(1558.0 / 8000.0, 4),
                   "hbm_bytes_per_launch": 77900000000}
