@@ -111,6 +111,12 @@ def test_full_build_description_compiles_every_kernel_source():
             if src.endswith(".hip"):
                 assert src in rules, src
         assert "--offload-arch=gfx950" in rules and "-ffp-contract=off" in rules and "libmm_gemm_amd.so" in rules
+        # the two units of the k-ordered contract (the reference's unfused Naive) are the ones compiled with contraction off
+        for unit in ("mm_ordered.hip", "mm_valu_tile_fp_exact.hip"):
+            cmds = [ln for ln in rules.split("\n") if "hipcc" in ln and f"-c {ROOT}/gemm_hls_amd/csrc/{unit}" in ln]
+            assert cmds and all("-ffp-contract=off" in ln for ln in cmds), unit
+        fast = [ln for ln in rules.split("\n") if "hipcc" in ln and f"-c {ROOT}/gemm_hls_amd/csrc/mm_valu_tile_fp.hip" in ln]
+        assert fast and not any("-ffp-contract=off" in ln for ln in fast)
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/host"), reason="needs the reference checkout (not present on the GPU box)")
