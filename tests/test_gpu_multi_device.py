@@ -264,6 +264,13 @@ def test_multi_device_c5a_real_size_eight_virtual_devices_sampled_rows():
     side of each slab boundary) against fp64, and -- whole output, 4 GiB -- bit for bit against the one-device launch."""
     import torch
     n, k, m, G = 65536, 16384, 16384, 8
+    try:
+        import psutil
+        free_gib = psutil.virtual_memory().available / 2 ** 30
+    except Exception:
+        free_gib = None
+    if free_gib is not None and free_gib < 24:
+        pytest.skip(f"needs ~14 GiB of host memory for A, B and two copies of C (a strike-proof margin of 24 GiB); {free_gib:.0f} GiB available")
     rng = np.random.default_rng(65)
     b = rng.uniform(1, 10, size=(k, m)).astype(np.float32)
     a = np.empty((n, k), np.float32)
