@@ -6,7 +6,6 @@ matrix on ragged and aligned shapes (device-side comparison of the whole output)
   python tools/ordered_tile_check.py [--sizes 4096,8192] [--reps 3]
 """
 import argparse
-import ctypes
 import os
 import sys
 
