@@ -230,3 +230,14 @@ def test_reference_hosts_no_transposed_blas_build():
     sys.path.insert(0, os.path.join(ROOT, "tests", "ref_hosts"))
     import build_ref_hosts
     assert not any(name.endswith("_blas") and cfg[3] for name, cfg in build_ref_hosts.CONFIGS.items())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("config", ["float", "float_blas"])
+def test_reference_test_simulation_at_baseline_c1_size(config):
+    """BASELINE configs[0] is `float 1024x1024x1024 via ... TestSimulation`: the reference's own test/TestSimulation.cpp, unmodified,
+    at that size, with MatrixMultiplicationKernel bound to the MI355X kernel library instead of the hlslib simulation -- verified by
+    its own ReferenceImplementation (the Naive fall-back in the plain build, cblas_sgemm in the -DMM_HAS_BLAS build) and its own rule."""
+    r = _run(config, "TestSimulation.exe", 1024, 1024, 1024)
+    assert r.returncode == 0 and "Matrix-matrix multiplication successfully verified." in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    assert ("Running BLAS..." in r.stdout) == (config == "float_blas")
